@@ -1,0 +1,117 @@
+/*
+ * pbr_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * A scalar C restatement of the reference renderer's IBL-precompute and shade-pass arithmetic,
+ * written from scratch by reading the reference's GLSL/C sources (cited per function in
+ * pbr_oracle.c).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * call into this library; the product (libgpu_hip.so) never links or loads it.
+ *
+ * Pinning: the Monte-Carlo maths is pinned by known-answer vectors obtained by executing the
+ * reference's own shader text on the CPU (tests/golden/oracle_a_*.json|npy, generator
+ * oracle/gen_oracle_a.py, values also listed in SURVEY.md 8c).  Texture filtering
+ * (seamless-cube bilinear, 2:1 blit) is implementation-defined in Vulkan and the reference
+ * has no tests: that part is "parity unpinned" and fixed by the definitions in pbr_oracle.c.
+ */
+#ifndef PBR_ORACLE_H
+#define PBR_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirrors RendererGlobalsBuffer (reference src/demo_pbr_renderer/render.h:122-136); 552 bytes.
+ * Matrices are column-major float[16] (HMM_Mat4: Elements[col][row]). */
+typedef struct OrcGlobals {
+    float clip_space_from_world[16];
+    float clip_space_from_view[16];
+    float world_space_from_clip[16];
+    float view_space_from_clip[16];
+    float view_space_from_world[16];
+    float world_space_from_view[16];
+    float sun_space_from_world[16];
+    float old_clip_space_from_world[16];
+    float sun_direction[4];
+    float camera_pos[3];
+    float frame_idx_mod_59;
+    float lightgrid_scale;
+    uint32_t visualize_lightgrid;
+} OrcGlobals;
+
+enum {
+    ORC_SHADE_IBL       = 1 << 0, /* ambient = irradiance(N), spec = prefiltered(R, rough*4) (lighting_pass.glsl:690,699) */
+    ORC_SHADE_SHAFTS    = 1 << 1, /* light-shaft loop with visibility == 1 (lighting_pass.glsl:622-651) */
+    ORC_SHADE_ANALYTIC  = 1 << 2  /* analytic stand-ins for the env/irradiance/prefiltered/LUT textures */
+};
+
+void   orc_set_threads(int n);
+int    orc_get_threads(void);
+
+/* ---- A1: Radiance RGBE decode (stb_image.h:7130-7286 semantics) ---- */
+/* Returns 0 on success. If out_rgba==NULL only w/h are reported. out_rgba holds w*h*4 floats. */
+int    orc_rgbe_decode(const uint8_t* bytes, size_t n, int* w, int* h, float* out_rgba);
+
+/* ---- A2: cube pyramid ---- */
+int    orc_mip_count(int w, int h);                 /* gpu_vulkan.c:1344-1351 */
+size_t orc_level_offset(int W, int level);          /* float offset of level in [level][face][y][x][4] */
+size_t orc_pyramid_floats(int W);
+void   orc_build_pyramid(float* pyr, int W);        /* level 0 present; fills levels 1.. (gpu_vulkan.c:1458-1483) */
+
+/* ---- cube sampling: seamless bilinear, trilinear across integer levels ---- */
+void   orc_face_dir(int face, float u, float v, float out[3]);   /* A3 */
+void   orc_cube_sample(const float* pyr, int W, int levels, const float dir[3], float lod, float out[4]);
+/* neighbour texel across a face edge (exactly one of i,j out of range): returns face', writes i',j' */
+int    orc_cube_neighbor(int face, int n, int i, int j, int* ni, int* nj);
+/* analytic environment of SURVEY 8c: (1+.5dx, 1+.5dy^2, 1+.5dz*dx, 1), d normalised */
+void   orc_env_analytic(const float dir[3], float out[4]);
+
+/* ---- A4/A5: per-sample tables (Fibonacci hemisphere; Beckmann weights) ---- */
+/* cs[i*4+0..3] = cos(pitch_i), sin(pitch_i), cos(yaw_i), sin(yaw_i)  (gen_prefiltered_env_map.glsl:125-128) */
+void   orc_sample_angles(int nsamples, float* cs);
+/* D_i = DistributionBeckmann(cos(pitch_i*0.5), roughness) (gen_prefiltered_env_map.glsl:86-91,141) */
+void   orc_prefilter_D(int nsamples, float roughness, float* D);
+
+/* ---- A5: specular prefilter, one mip ---- */
+/* pyr==NULL -> analytic env.  mip==0 -> copy of env LOD `src_lod` (reference: 1.0).
+ * Writes faces [face0,face1) rows [y0,y1) into out (full [6][out_size][out_size][4] array). */
+void   orc_prefilter_mip(const float* pyr, int W, int levels, int out_size, int mip, float roughness,
+                         float src_lod, int nsamples, int literal,
+                         int face0, int face1, int y0, int y1, float* out);
+
+/* ---- A6: irradiance ---- */
+void   orc_irradiance(const float* pyr, int W, int levels, int out_size, float src_lod, int nsamples,
+                      int literal, int face0, int face1, int y0, int y1, float* out);
+
+/* ---- A7: split-sum LUT; out holds size*size*2 floats (scale,bias), rows [y0,y1) ---- */
+void   orc_brdf_lut(int size, int nsamples, int y0, int y1, float* out_rg);
+
+/* ---- fp16 helpers (RTE) ---- */
+uint16_t orc_f32_to_f16(float f);
+float    orc_f16_to_f32(uint16_t h);
+
+/* ---- A8: shade pass ---- */
+typedef struct OrcShadeInputs {
+    int width, height;
+    const uint8_t* base_color;   /* [H][W][4] unorm8 */
+    const uint8_t* normal;       /* [H][W][4] unorm8 */
+    const uint8_t* orm;          /* [H][W][4] unorm8 */
+    const uint8_t* emissive;     /* [H][W][4] unorm8 */
+    const float*   depth;        /* [H][W] */
+    const float*   irradiance;   /* cube, 1 level, RGBA32F; may be NULL with ORC_SHADE_ANALYTIC or without IBL */
+    int            irradiance_size;
+    const float*   prefiltered;  /* cube pyramid RGBA32F */
+    int            prefiltered_size, prefiltered_levels;
+    const uint16_t* lut;         /* [S][S][2] fp16 */
+    int            lut_size;
+} OrcShadeInputs;
+
+/* out_rgba: [H][W][4] fp32 (pre-quantisation); rows [y0,y1), columns [x0,x1) are written. */
+void   orc_shade(const OrcGlobals* g, const OrcShadeInputs* in, int flags,
+                 int x0, int x1, int y0, int y1, float* out_rgba);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

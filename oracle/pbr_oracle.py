@@ -1,0 +1,259 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg as the checker / reported baseline -- never by the product path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+class OrcGlobals(C.Structure):
+    _fields_ = [
+        ("clip_space_from_world", C.c_float * 16),
+        ("clip_space_from_view", C.c_float * 16),
+        ("world_space_from_clip", C.c_float * 16),
+        ("view_space_from_clip", C.c_float * 16),
+        ("view_space_from_world", C.c_float * 16),
+        ("world_space_from_view", C.c_float * 16),
+        ("sun_space_from_world", C.c_float * 16),
+        ("old_clip_space_from_world", C.c_float * 16),
+        ("sun_direction", C.c_float * 4),
+        ("camera_pos", C.c_float * 3),
+        ("frame_idx_mod_59", C.c_float),
+        ("lightgrid_scale", C.c_float),
+        ("visualize_lightgrid", C.c_uint32),
+    ]
+
+
+assert C.sizeof(OrcGlobals) == 552
+
+
+class OrcShadeInputs(C.Structure):
+    _fields_ = [
+        ("width", C.c_int), ("height", C.c_int),
+        ("base_color", C.c_void_p), ("normal", C.c_void_p), ("orm", C.c_void_p),
+        ("emissive", C.c_void_p), ("depth", C.c_void_p),
+        ("irradiance", C.c_void_p), ("irradiance_size", C.c_int),
+        ("prefiltered", C.c_void_p), ("prefiltered_size", C.c_int), ("prefiltered_levels", C.c_int),
+        ("lut", C.c_void_p), ("lut_size", C.c_int),
+    ]
+
+
+SHADE_IBL, SHADE_SHAFTS, SHADE_ANALYTIC = 1, 2, 4
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liborc.so")
+    src = os.path.join(_HERE, "pbr_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "liborc.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    L = C.CDLL(build())
+    L.orc_set_threads.argtypes = [C.c_int]
+    L.orc_get_threads.restype = C.c_int
+    L.orc_rgbe_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
+    L.orc_rgbe_decode.restype = C.c_int
+    L.orc_mip_count.argtypes = [C.c_int, C.c_int]
+    L.orc_mip_count.restype = C.c_int
+    L.orc_level_offset.argtypes = [C.c_int, C.c_int]
+    L.orc_level_offset.restype = C.c_size_t
+    L.orc_pyramid_floats.argtypes = [C.c_int]
+    L.orc_pyramid_floats.restype = C.c_size_t
+    L.orc_build_pyramid.argtypes = [f32p, C.c_int]
+    L.orc_face_dir.argtypes = [C.c_int, C.c_float, C.c_float, f32p]
+    L.orc_cube_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, C.c_float, f32p]
+    L.orc_cube_neighbor.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_cube_neighbor.restype = C.c_int
+    L.orc_env_analytic.argtypes = [f32p, f32p]
+    L.orc_sample_angles.argtypes = [C.c_int, f32p]
+    L.orc_prefilter_D.argtypes = [C.c_int, C.c_float, f32p]
+    L.orc_prefilter_mip.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+    L.orc_irradiance.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+    L.orc_brdf_lut.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+    L.orc_f32_to_f16.argtypes = [C.c_float]
+    L.orc_f32_to_f16.restype = C.c_uint16
+    L.orc_f16_to_f32.argtypes = [C.c_uint16]
+    L.orc_f16_to_f32.restype = C.c_float
+    L.orc_shade.argtypes = [C.POINTER(OrcGlobals), C.POINTER(OrcShadeInputs), C.c_int,
+                            C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+    _LIB = L
+    return L
+
+
+# ---- reference parameter rules (host side of the reference + SURVEY 8d extension) -------------
+REF_ROUGHNESS = (0.0, 0.03, 0.15, 0.4, 0.6)   # gen_prefiltered_env_map.glsl:117
+
+
+def prefilter_roughness(mip):
+    """mips 0-4: reference table; mips >= 5: documented extension min(1, 0.6 + 0.08*(m-4))."""
+    if mip < 5:
+        return float(np.float32(REF_ROUGHNESS[mip]))
+    return float(min(np.float32(1.0), np.float32(0.6) + np.float32(0.08) * np.float32(mip - 4)))
+
+
+def prefilter_src_lod(mip):
+    """gen_prefiltered_env_map.glsl:113 (mip 0 -> lod 1) and :138 (3 + mip); sampler clamps to last level."""
+    return 1.0 if mip == 0 else 3.0 + mip
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
+def get_threads():
+    return lib().orc_get_threads()
+
+
+def mip_count(w, h=None):
+    return lib().orc_mip_count(int(w), int(w if h is None else h))
+
+
+def level_offset(W, level):
+    return lib().orc_level_offset(int(W), int(level))
+
+
+def pyramid_floats(W):
+    return lib().orc_pyramid_floats(int(W))
+
+
+def build_pyramid(level0):
+    """level0: float32 [6][W][W][4] -> flat float32 pyramid [level][face][y][x][4]."""
+    level0 = np.ascontiguousarray(level0, dtype=np.float32)
+    W = level0.shape[1]
+    assert level0.shape == (6, W, W, 4)
+    pyr = np.zeros(pyramid_floats(W), dtype=np.float32)
+    pyr[: level0.size] = level0.ravel()
+    lib().orc_build_pyramid(pyr, W)
+    return pyr
+
+
+def pyramid_level(pyr, W, level):
+    n = max(1, W >> level)
+    off = level_offset(W, level)
+    return pyr[off: off + 6 * n * n * 4].reshape(6, n, n, 4)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def cube_sample(pyr, W, dirs, lod):
+    dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+    levels = mip_count(W) if pyr is not None else 1
+    out = np.zeros((dirs.shape[0], 4), dtype=np.float32)
+    L = lib()
+    for k in range(dirs.shape[0]):
+        L.orc_cube_sample(_ptr(pyr), W, levels, dirs[k], float(lod), out[k])
+    return out
+
+
+def rgbe_decode(data: bytes):
+    w, h = C.c_int(), C.c_int()
+    rc = lib().orc_rgbe_decode(data, len(data), C.byref(w), C.byref(h), None)
+    if rc:
+        raise ValueError(f"rgbe decode failed: {rc}")
+    out = np.zeros((h.value, w.value, 4), dtype=np.float32)
+    rc = lib().orc_rgbe_decode(data, len(data), C.byref(w), C.byref(h), out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise ValueError(f"rgbe decode failed: {rc}")
+    return out
+
+
+def prefilter_mip(pyr, W, out_size, mip, roughness=None, src_lod=None, nsamples=8192, literal=False,
+                  faces=(0, 6), rows=None, levels=None):
+    size = max(1, out_size >> mip)
+    if roughness is None:
+        roughness = prefilter_roughness(mip)
+    if src_lod is None:
+        src_lod = prefilter_src_lod(mip)
+    if rows is None:
+        rows = (0, size)
+    if levels is None:
+        levels = mip_count(W) if pyr is not None else 1
+    out = np.zeros((6, size, size, 4), dtype=np.float32)
+    lib().orc_prefilter_mip(_ptr(pyr), W, levels, size, mip, roughness, src_lod, nsamples, int(literal),
+                            faces[0], faces[1], rows[0], rows[1], out)
+    return out
+
+
+def irradiance(pyr, W, out_size=32, src_lod=6.0, nsamples=1024, literal=False, faces=(0, 6), rows=None):
+    if rows is None:
+        rows = (0, out_size)
+    levels = mip_count(W) if pyr is not None else 1
+    out = np.zeros((6, out_size, out_size, 4), dtype=np.float32)
+    lib().orc_irradiance(_ptr(pyr), W, levels, out_size, src_lod, nsamples, int(literal),
+                         faces[0], faces[1], rows[0], rows[1], out)
+    return out
+
+
+def brdf_lut(size=256, nsamples=4096, rows=None):
+    if rows is None:
+        rows = (0, size)
+    out = np.zeros((size, size, 2), dtype=np.float32)
+    lib().orc_brdf_lut(size, nsamples, rows[0], rows[1], out)
+    return out
+
+
+def f32_to_f16_bits(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    L = lib()
+    return np.array([L.orc_f32_to_f16(float(v)) for v in a.ravel()], dtype=np.uint16).reshape(a.shape)
+
+
+def make_globals(mats: dict, sun_direction, camera_pos, frame_idx_mod_59=0.0, lightgrid_scale=1.0 / 40.0):
+    g = OrcGlobals()
+    for name, _ in OrcGlobals._fields_[:8]:
+        m = np.asarray(mats.get(name, np.eye(4, dtype=np.float32).T.ravel()), dtype=np.float32).ravel()
+        getattr(g, name)[:] = m.tolist()
+    sd = list(sun_direction) + [0.0] * (4 - len(sun_direction))
+    g.sun_direction[:] = [float(v) for v in sd]
+    g.camera_pos[:] = [float(v) for v in camera_pos]
+    g.frame_idx_mod_59 = float(frame_idx_mod_59)
+    g.lightgrid_scale = float(lightgrid_scale)
+    g.visualize_lightgrid = 0
+    return g
+
+
+def shade(g, base, normal, orm, emissive, depth, flags=0, irradiance_cube=None, prefiltered_pyr=None,
+          prefiltered_size=0, lut_half=None, region=None):
+    H, W = depth.shape
+    keep = [np.ascontiguousarray(a, dtype=np.uint8) for a in (base, normal, orm, emissive)]
+    depth = np.ascontiguousarray(depth, dtype=np.float32)
+    si = OrcShadeInputs()
+    si.width, si.height = W, H
+    si.base_color, si.normal, si.orm, si.emissive = [_ptr(a) for a in keep]
+    si.depth = _ptr(depth)
+    if irradiance_cube is not None:
+        irradiance_cube = np.ascontiguousarray(irradiance_cube, dtype=np.float32)
+        si.irradiance = _ptr(irradiance_cube)
+        si.irradiance_size = irradiance_cube.shape[1]
+    if prefiltered_pyr is not None:
+        prefiltered_pyr = np.ascontiguousarray(prefiltered_pyr, dtype=np.float32)
+        si.prefiltered = _ptr(prefiltered_pyr)
+        si.prefiltered_size = prefiltered_size
+        si.prefiltered_levels = mip_count(prefiltered_size)
+    if lut_half is not None:
+        lut_half = np.ascontiguousarray(lut_half, dtype=np.uint16)
+        si.lut = _ptr(lut_half)
+        si.lut_size = lut_half.shape[0]
+    out = np.zeros((H, W, 4), dtype=np.float32)
+    x0, x1, y0, y1 = region if region is not None else (0, W, 0, H)
+    lib().orc_shade(C.byref(g), C.byref(si), int(flags), x0, x1, y0, y1, out)
+    return out
