@@ -1,0 +1,394 @@
+#!/usr/bin/env python3
+"""Oracle-A: execute the REFERENCE's shader text on the CPU and commit the numbers.
+
+Runs only in the build container (needs /root/reference).  For each hot-path shader it
+  1. reads the .glsl text where it lies under /root/reference (nothing is copied into the repo),
+  2. applies the mechanical text edits of SURVEY.md Appendix B (decl qualifiers -> `static`, f-suffix
+     on decimal literals so C++ keeps fp32, `.xyz` -> `.xyz()`, `main` -> `shader_main`),
+  3. compiles the result against oracle/glsl_shim.hpp with g++ (scratch dir under /tmp),
+  4. drives shader_main() per invocation and stores what imageStore()/out_color receive.
+Outputs: tests/golden/oracle_a_*.npy / .json  (data only).
+
+What this pins: all shader arithmetic (sample generation, Rotate, Beckmann/GGX/Mikkelsen/Schlick,
+accumulation order, G-buffer decode, position reconstruction, noise, composition).
+What it cannot pin: texture filtering -- the reference delegates it to the Vulkan driver; here
+textureLod() is routed to the analytic environment or to the oracle's own sampler (stated per fixture).
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("PBR_REFERENCE", "/root/reference")
+SHADERS = os.path.join(REF, "src/demo_pbr_renderer/shaders")
+SCRATCH = os.environ.get("ORACLE_A_SCRATCH", "/tmp/oracle_a")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "vulkan-pbr-renderer_amd", "python"))
+
+TEX_IDS = {
+    "TEX_ENV_CUBE": 1, "GBUFFER_BASE_COLOR": 10, "GBUFFER_NORMAL": 11, "GBUFFER_ORM": 12,
+    "GBUFFER_EMISSIVE": 13, "GBUFFER_DEPTH": 14, "PREV_FRAME_RESULT": 15, "TEX_IRRADIANCE_MAP": 20,
+    "PREFILTERED_ENV_MAP": 21, "BRDF_INTEGRATION_MAP": 22, "SUN_DEPTH_MAP": 23, "LIGHTGRID": 24,
+}
+
+FLOAT_LIT = re.compile(r"(?<![\w.])(\d+\.\d*(?:[eE][+-]?\d+)?|\.\d+(?:[eE][+-]?\d+)?|\d+[eE][+-]?\d+)(?![\w.])")
+
+
+def preprocess(text, lighting_variant=None):
+    lines = text.split("\n")
+    if lighting_variant is not None:
+        def blank(a, b):                      # 1-based inclusive
+            for k in range(a - 1, b):
+                lines[k] = ""
+        assert "MurmurHash31" in lines[121] or "MurmurHash" in "".join(lines[121:147]), "reference changed"
+        blank(122, 147)                       # dead hash helpers
+        assert "bayerIndex" in lines[425]
+        blank(426, 430)
+        assert "bayer_coord" in lines[563] and "noise_constant" in lines[564]
+        blank(564, 565)
+        assert "sun_p.xy +=" in lines[599]
+        lines[599] = ("sun_p.x += (2.*vec2(noise_2 - 0.5, noise_1 - 0.5) * sun_shadow_map_pixel_size).x; "
+                      "sun_p.y += (2.*vec2(noise_2 - 0.5, noise_1 - 0.5) * sun_shadow_map_pixel_size).y;")
+        assert lines[621].strip() == "#if 1"
+        if lighting_variant in ("live_noshaft", "ibl"):
+            lines[621] = "#if 0"
+        if lighting_variant == "ibl":         # Oracle-A': un-comment the IBL lines (reference-derived, not live)
+            assert "SampleRadianceWithScreenSpaceTrace" in lines[684] and "irradiance" in lines[689]
+            rhs690 = lines[689].split("=", 1)[1].replace("//", "").strip()
+            lines[684] = "ambient = " + rhs690
+            assert "SampleRadianceWithScreenSpaceTrace" in lines[700] and "prefilter_spec_color" in lines[698]
+            rhs699 = lines[698].split("=", 1)[1].strip()
+            lines[700] = "prefilter_spec_color = " + rhs699
+    t = "\n".join(lines)
+    t = re.sub(r"^layout\s*\(local_size.*$", "", t, flags=re.M)
+
+    def binding(m):
+        ind, name, typ, var = m.group(1), m.group(2), m.group(3), m.group(4)
+        if typ in ("imageCube", "image2D"):
+            return f"{ind}static {typ} {var};"
+        return f"{ind}static {typ} {var} = {{{TEX_IDS.get(name, 0)}}};"
+    t = re.sub(r"^(\s*)GPU_BINDING\((\w+)\)\s+(\w+)\s+(\w+);", binding, t, flags=re.M)
+    t = re.sub(r"GPU_BINDING\(GLOBALS\)\s*\{", "static struct {", t)
+    t = re.sub(r"layout\(push_constant\)\s*uniform\s+\w+\s*\{", "static struct {", t)
+    t = re.sub(r"layout\(location\s*=\s*\d+\)\s*(in|out)\s+", "static ", t)
+    t = FLOAT_LIT.sub(r"\1f", t)
+    t = re.sub(r"\.(xyz|rgb|xy)\b", r".\1()", t)
+    t = t.replace("void main()", "void shader_main()")
+    return t
+
+
+DRIVER_COMMON = r"""
+#include "glsl_shim.hpp"
+extern "C" {
+#include "pbr_oracle.h"
+}
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+vec4 (*shim_cube_lookup)(int, vec3, float);
+vec4 (*shim_tex2d_lookup)(int, vec2, float);
+static std::vector<float> load_f32(const char* path) {
+    FILE* f = fopen(path, "rb"); if (!f) { perror(path); exit(2); }
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<float> v(n / 4); if (fread(v.data(), 1, n, f) != (size_t)n) exit(3); fclose(f); return v;
+}
+static void save_f32(const char* path, const float* d, size_t n) {
+    FILE* f = fopen(path, "wb"); fwrite(d, 4, n, f); fclose(f);
+}
+"""
+
+DRIVER_COMPUTE = DRIVER_COMMON + r"""
+namespace S {
+#include "SHADER_INC"
+}
+static std::vector<float> g_pyr; static int g_W = 1, g_levels = 1; static bool g_analytic = true;
+static vec4 cube_cb(int, vec3 d, float lod) {
+    float dd[3] = {d.x, d.y, d.z}, o[4];
+    orc_cube_sample(g_analytic ? nullptr : g_pyr.data(), g_W, g_levels, dd, lod, o);
+    return vec4(o[0], o[1], o[2], o[3]);
+}
+// argv: out_size mip env(analytic|path) W face0 face1 y0 y1 out_path
+int main(int argc, char** argv) {
+    if (argc < 10) return 1;
+    int size = atoi(argv[1]); int mip = atoi(argv[2]);
+    g_analytic = strcmp(argv[3], "analytic") == 0; g_W = atoi(argv[4]);
+    if (!g_analytic) { g_pyr = load_f32(argv[3]); g_levels = orc_mip_count(g_W, g_W); }
+    int f0 = atoi(argv[5]), f1 = atoi(argv[6]), y0 = atoi(argv[7]), y1 = atoi(argv[8]);
+    shim_cube_lookup = cube_cb;
+    (void)mip;
+#if defined(KIND_LUT)
+    std::vector<float> out((size_t)size * size * 4, 0.f);
+    S::OUTPUT.size = size; S::OUTPUT.data = out.data();
+    for (int y = y0; y < y1; y++) for (int x = 0; x < size; x++) {
+        gl_GlobalInvocationID = uvec3{(uint)x, (uint)y, 0u}; S::shader_main();
+    }
+#else
+    std::vector<float> out((size_t)6 * size * size * 4, 0.f);
+    S::OUTPUT.size = size; S::OUTPUT.data = out.data();
+#if defined(KIND_PREFILTER)
+    S::constants.mip_level = mip;
+#endif
+    for (int f = f0; f < f1; f++) for (int y = y0; y < y1; y++) for (int x = 0; x < size; x++) {
+        gl_GlobalInvocationID = uvec3{(uint)x, (uint)y, (uint)f}; S::shader_main();
+    }
+#endif
+    save_f32(argv[9], out.data(), out.size());
+    return 0;
+}
+"""
+
+DRIVER_LIGHTING = DRIVER_COMMON + r"""
+namespace S {
+#include "SHADER_INC"
+}
+struct PixelRec { int x, y; unsigned char base[4], nrm[4], orm[4], emi[4]; float depth; };
+static PixelRec g_px;
+static int g_mode = 0;   // 0: analytic live (prefiltered = env), 1: analytic A' stand-ins, 2: textured
+static std::vector<float> g_irr, g_pre, g_lutf; static std::vector<uint16_t> g_lut;
+static int g_irr_size = 0, g_pre_size = 0, g_lut_size = 0;
+static vec4 env(vec3 d) { float dd[3] = {d.x, d.y, d.z}, o[4]; orc_env_analytic(dd, o); return vec4(o[0], o[1], o[2], o[3]); }
+static vec4 cube_cb(int id, vec3 d, float lod) {
+    float dd[3] = {d.x, d.y, d.z}, o[4];
+    if (g_mode == 2) {
+        if (id == 20) orc_cube_sample(g_irr.data(), g_irr_size, 1, dd, lod, o);
+        else orc_cube_sample(g_pre.data(), g_pre_size, orc_mip_count(g_pre_size, g_pre_size), dd, lod, o);
+        return vec4(o[0], o[1], o[2], o[3]);
+    }
+    if (g_mode == 1) { if (id == 20) return 0.5f * env(d); return env(d) * (1.0f - 0.1f * lod); }
+    return env(d);
+}
+static vec4 u8v(const unsigned char* p) { return vec4(p[0] / 255.0f, p[1] / 255.0f, p[2] / 255.0f, p[3] / 255.0f); }
+static vec4 tex2d_cb(int id, vec2 uv, float) {
+    switch (id) {
+    case 10: return u8v(g_px.base);
+    case 11: return u8v(g_px.nrm);
+    case 12: return u8v(g_px.orm);
+    case 13: return u8v(g_px.emi);
+    case 14: return vec4(g_px.depth, 0.f, 0.f, 1.f);
+    case 22:
+        if (g_mode == 2) { float o[2]; orc_lut_sample(g_lut.data(), g_lut_size, uv.x, uv.y, o); return vec4(o[0], o[1], 0.f, 1.f); }
+        return vec4(0.9f - 0.5f * uv.y, 0.02f + 0.1f * (1.0f - uv.x), 0.f, 1.f);
+    default: return vec4(0.f);   // PREV_FRAME_RESULT, SUN_DEPTH_MAP as colour: 0
+    }
+}
+// argv: mode W H globals.bin pixels.bin out.bin [irr.bin irr_size pre.bin pre_size lut_f32.bin lut_size]
+int main(int argc, char** argv) {
+    if (argc < 7) return 1;
+    g_mode = atoi(argv[1]); int W = atoi(argv[2]), H = atoi(argv[3]);
+    std::vector<float> gl = load_f32(argv[4]);
+    memcpy(&S::GLOBALS.data, gl.data(), 552);
+    if (g_mode == 2) {
+        g_irr = load_f32(argv[7]); g_irr_size = atoi(argv[8]);
+        g_pre = load_f32(argv[9]); g_pre_size = atoi(argv[10]);
+        g_lutf = load_f32(argv[11]); g_lut_size = atoi(argv[12]);
+        g_lut.resize(g_lutf.size());
+        for (size_t i = 0; i < g_lutf.size(); i++) g_lut[i] = orc_f32_to_f16(g_lutf[i]);
+    }
+    FILE* f = fopen(argv[5], "rb"); fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<PixelRec> px(n / sizeof(PixelRec)); if (fread(px.data(), 1, n, f) != (size_t)n) return 3; fclose(f);
+    shim_cube_lookup = cube_cb; shim_tex2d_lookup = tex2d_cb;
+    std::vector<float> out(px.size() * 4);
+    for (size_t i = 0; i < px.size(); i++) {
+        g_px = px[i];
+        S::fs_uv = vec2((px[i].x + 0.5f) / (float)W, (px[i].y + 0.5f) / (float)H);
+        gl_FragCoord = vec4(px[i].x + 0.5f, px[i].y + 0.5f, px[i].depth, 1.0f);
+        S::shader_main();
+        out[i * 4 + 0] = S::out_color.x; out[i * 4 + 1] = S::out_color.y; out[i * 4 + 2] = S::out_color.z; out[i * 4 + 3] = S::out_color.w;
+    }
+    save_f32(argv[6], out.data(), out.size());
+    return 0;
+}
+"""
+
+CXX = ["g++", "-std=c++17", "-O2", "-fno-fast-math", "-ffp-contract=off", "-w", f"-I{HERE}"]
+
+
+def build(name, glsl, driver, defines=(), lighting_variant=None):
+    os.makedirs(SCRATCH, exist_ok=True)
+    with open(os.path.join(SHADERS, glsl)) as f:
+        text = f.read()
+    inc = os.path.join(SCRATCH, name + ".inc")
+    with open(inc, "w") as f:
+        f.write(preprocess(text, lighting_variant))
+    src = os.path.join(SCRATCH, name + ".cpp")
+    with open(src, "w") as f:
+        f.write(driver.replace("SHADER_INC", inc))
+    exe = os.path.join(SCRATCH, name)
+    obj = os.path.join(SCRATCH, "pbr_oracle.o")
+    if not os.path.exists(obj):
+        subprocess.check_call(["gcc", "-O2", "-fno-fast-math", "-ffp-contract=off", "-std=c11", "-c",
+                               os.path.join(HERE, "pbr_oracle.c"), "-o", obj])
+    subprocess.check_call(CXX + [f"-D{d}" for d in defines] + [src, obj, "-lm", "-o", exe])
+    return exe
+
+
+def run_compute(exe, size, mip, env, W, faces=(0, 6), rows=None, cube=True, nproc=8):
+    """Split rows over processes; returns [6][size][size][4] (or [size][size][4] for the LUT)."""
+    rows = rows or (0, size)
+    nrows = rows[1] - rows[0]
+    nproc = max(1, min(nproc, nrows))
+    cuts = [rows[0] + (nrows * k) // nproc for k in range(nproc + 1)]
+    shape = (6, size, size, 4) if cube else (size, size, 4)
+    outs = []
+
+    def job(k):
+        outp = os.path.join(SCRATCH, f"out_{os.path.basename(exe)}_{os.getpid()}_{k}.bin")
+        subprocess.check_call([exe, str(size), str(mip), env, str(W), str(faces[0]), str(faces[1]),
+                               str(cuts[k]), str(cuts[k + 1]), outp])
+        a = np.fromfile(outp, dtype=np.float32).reshape(shape)
+        os.remove(outp)
+        return a
+    with ThreadPoolExecutor(nproc) as ex:
+        outs = list(ex.map(job, range(nproc)))
+    total = np.zeros(shape, np.float32)
+    for k, a in enumerate(outs):
+        if cube:
+            total[faces[0]:faces[1], cuts[k]:cuts[k + 1]] = a[faces[0]:faces[1], cuts[k]:cuts[k + 1]]
+        else:
+            total[cuts[k]:cuts[k + 1]] = a[cuts[k]:cuts[k + 1]]
+    return total
+
+
+PIXEL_DT = np.dtype([("x", "<i4"), ("y", "<i4"), ("base", "u1", 4), ("nrm", "u1", 4), ("orm", "u1", 4),
+                     ("emi", "u1", 4), ("depth", "<f4")])
+
+
+def run_lighting(exe, mode, W, H, globals_bytes, pixels, extra=()):
+    gp = os.path.join(SCRATCH, "globals.bin")
+    pp = os.path.join(SCRATCH, f"pixels_{os.getpid()}.bin")
+    op = os.path.join(SCRATCH, f"lit_{os.getpid()}.bin")
+    with open(gp, "wb") as f:
+        f.write(globals_bytes)
+    pixels.tofile(pp)
+    subprocess.check_call([exe, str(mode), str(W), str(H), gp, pp, op] + [str(e) for e in extra])
+    return np.fromfile(op, dtype=np.float32).reshape(-1, 4)
+
+
+def main():
+    import pbr_oracle as O
+    from pbrhip import synth
+    import ctypes as C
+
+    os.makedirs(GOLDEN, exist_ok=True)
+    meta = {"generator": "oracle/gen_oracle_a.py", "reference": "uuwee/Vulkan-PBR-Renderer @ 2025-08-08",
+            "note": "numbers produced by executing the reference GLSL text as C++ (glibc libm, fp32); "
+                    "texture lookups are analytic or the oracle's sampler, as named per entry"}
+
+    # ------------------------------------------------------------------ LUT (gen_brdf_integration_map.glsl)
+    lut_exe = build("lut", "gen_brdf_integration_map.glsl", DRIVER_COMPUTE, ["KIND_LUT"])
+    lut = run_compute(lut_exe, 256, 0, "analytic", 1, cube=False)
+    np.save(os.path.join(GOLDEN, "oracle_a_lut256.npy"), lut[..., :2].copy())
+    meta["lut256"] = {"file": "oracle_a_lut256.npy", "shape": [256, 256, 2], "store_ba": [float(lut[0, 0, 2]), float(lut[0, 0, 3])]}
+    print("LUT done", lut[128, 128])
+
+    # ------------------------------------------------------------------ prefilter, analytic env
+    pre_exe = build("prefilter", "gen_prefiltered_env_map.glsl", DRIVER_COMPUTE, ["KIND_PREFILTER"])
+    kats = []
+    for (mip, x, y, f) in [(0, 0, 0, 0), (1, 0, 0, 0), (1, 64, 17, 3), (2, 63, 0, 5), (3, 5, 20, 2), (4, 15, 15, 4), (4, 8, 3, 1),
+                           (0, 255, 128, 2), (1, 127, 127, 5), (2, 0, 63, 1)]:
+        size = 256 >> mip
+        a = run_compute(pre_exe, size, mip, "analytic", 1, faces=(f, f + 1), rows=(y, y + 1), nproc=1)
+        kats.append({"mip": mip, "x": x, "y": y, "face": f, "rgba": [float(v) for v in a[f, y, x]]})
+    meta["prefilter_analytic_kats"] = {"out_size": 256, "env": "analytic", "texels": kats}
+    for mip in (3, 4):
+        size = 256 >> mip
+        a = run_compute(pre_exe, size, mip, "analytic", 1)
+        np.save(os.path.join(GOLDEN, f"oracle_a_prefilter_analytic_mip{mip}.npy"), a)
+        print("prefilter analytic mip", mip, a.astype(np.float64).sum(axis=(0, 1, 2)))
+
+    # ------------------------------------------------------------------ irradiance, analytic env
+    irr_exe = build("irradiance", "gen_irradiance_map.glsl", DRIVER_COMPUTE, ["KIND_IRRADIANCE"])
+    a = run_compute(irr_exe, 32, 0, "analytic", 1)
+    np.save(os.path.join(GOLDEN, "oracle_a_irradiance_analytic.npy"), a)
+    print("irradiance analytic", a.astype(np.float64).sum(axis=(0, 1, 2)))
+
+    # ------------------------------------------------------------------ textured env (oracle sampler): W=64 and W=256
+    env64 = synth.synth_env(64, seed=0x5EED00AA)
+    pyr64 = O.build_pyramid(env64)
+    p64 = os.path.join(SCRATCH, "pyr64.bin")
+    pyr64.tofile(p64)
+    for mip in (0, 1, 2):
+        size = 64 >> mip
+        a = run_compute(pre_exe, size, mip, p64, 64)
+        np.save(os.path.join(GOLDEN, f"oracle_a_prefilter_env64_out64_mip{mip}.npy"), a)
+        print("prefilter env64 mip", mip, a.astype(np.float64).sum(axis=(0, 1, 2)))
+    env256 = synth.synth_env(256, seed=0x5EED00AB)
+    pyr256 = O.build_pyramid(env256)
+    p256 = os.path.join(SCRATCH, "pyr256.bin")
+    pyr256.tofile(p256)
+    a = run_compute(irr_exe, 32, 0, p256, 256)      # lod 6 of a 256 cube = 4x4 faces
+    np.save(os.path.join(GOLDEN, "oracle_a_irradiance_env256.npy"), a)
+    print("irradiance env256", a.astype(np.float64).sum(axis=(0, 1, 2)))
+    meta["textured"] = {"env64_seed": 0x5EED00AA, "env256_seed": 0x5EED00AB,
+                        "sampler": "oracle (pbr_oracle.c cube_sample); env from pbrhip.synth.synth_env"}
+
+    # ------------------------------------------------------------------ lighting pass
+    subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
+    R = C.CDLL(os.path.join(HERE, "_ref", "libref_thirdparty.so"))
+    gbuf = np.zeros(140, np.float32)
+    R.ref_fill_globals((C.c_float * 3)(0, 0, 5), (C.c_float * 4)(0, 0, 0, 1), 1, C.c_float(75), C.c_float(16 / 9),
+                       C.c_float(.02), C.c_float(1e4), C.c_float(56.5), C.c_float(97), 0, gbuf.ctypes.data_as(C.c_void_p))
+    gbytes = gbuf.tobytes()[:552]
+    np.save(os.path.join(GOLDEN, "ref_globals_default.npy"), gbuf[:138].copy())
+    meta["globals_default"] = {"file": "ref_globals_default.npy", "source": "oracle/_ref (HandmadeMath.h v2.0.0 from the reference) "
+                               "restating utils/camera.h:103-120 + render.cpp:962-991; pos=(0,0,5), default ori, fov 75, "
+                               "aspect 16/9, near .02, far 1e4, sun_angle (56.5, 97), frame 0", "floats": 138}
+    px = np.zeros(5, PIXEL_DT)
+    rows = [
+        (960, 540, (204, 153, 51), (230, 40, 200), (255, 64, 0), (0, 0, 0), 0.9990),
+        (100, 900, (255, 255, 255), (200, 60, 220), (255, 26, 255), (0, 0, 0), 0.9985),
+        (1800, 100, (128, 128, 128), (128, 10, 240), (255, 204, 128), (25, 12, 0), 0.9995),
+        (500, 300, (51, 102, 204), (128, 0, 128), (255, 128, 0), (0, 0, 0), 0.9990),
+        (1000, 200, (0, 0, 0), (0, 0, 0), (0, 0, 0), (0, 0, 0), 1.0),
+    ]
+    for k, (x, y, b, n, o, e, d) in enumerate(rows):
+        px[k]["x"], px[k]["y"] = x, y
+        px[k]["base"][:3], px[k]["nrm"][:3], px[k]["orm"][:3], px[k]["emi"][:3] = b, n, o, e
+        px[k]["base"][3] = px[k]["nrm"][3] = px[k]["orm"][3] = px[k]["emi"][3] = 255 if k < 4 else 0
+        px[k]["depth"] = d
+    lit = {}
+    exes = {}
+    for variant in ("live_noshaft", "live_shaft", "ibl"):
+        exes[variant] = build("lighting_" + variant, "lighting_pass.glsl", DRIVER_LIGHTING, lighting_variant=variant)
+        mode = 1 if variant == "ibl" else 0
+        lit[variant] = run_lighting(exes[variant], mode, 1920, 1080, gbytes, px).tolist()
+        print(variant, lit[variant])
+    meta["lighting_kats"] = {"width": 1920, "height": 1080, "pixels": [
+        {"x": r[0], "y": r[1], "base": r[2], "normal": r[3], "orm": r[4], "emissive": r[5], "depth": r[6]} for r in rows],
+        "alpha_bytes": [255, 255, 255, 255, 0], "results": lit,
+        "stand_ins": "env(d)=(1+.5dx,1+.5dy^2,1+.5dz*dx,1); live: prefiltered=env; ibl: irradiance=.5env, "
+                     "prefiltered=env*(1-.1lod), LUT(u,v)=(.9-.5v,.02+.1(1-u)); light grid 0, shadow 1, prev frame 0"}
+
+    # a seeded random tile (analytic stand-ins): 64x36 pixels spread over the 1920x1080 frame, incl. sky
+    rng = np.random.default_rng(0x5EED00AC)
+    n = 64 * 36
+    tile = np.zeros(n, PIXEL_DT)
+    tile["x"] = rng.integers(0, 1920, n)
+    tile["y"] = rng.integers(0, 1080, n)
+    for key in ("base", "nrm", "orm", "emi"):
+        tile[key] = rng.integers(0, 256, (n, 4))
+    tile["emi"][rng.random(n) > 0.1] = 0
+    tile["depth"] = (0.9980 + 0.0019 * rng.random(n)).astype(np.float32)
+    tile["depth"][rng.random(n) < 0.1] = 1.0
+    np.save(os.path.join(GOLDEN, "oracle_a_lighting_tile_inputs.npy"), tile)
+    for variant in ("live_noshaft", "live_shaft", "ibl"):
+        mode = 1 if variant == "ibl" else 0
+        out = run_lighting(exes[variant], mode, 1920, 1080, gbytes, tile)
+        np.save(os.path.join(GOLDEN, f"oracle_a_lighting_tile_{variant}.npy"), out)
+    meta["lighting_tile"] = {"inputs": "oracle_a_lighting_tile_inputs.npy", "seed": 0x5EED00AC, "count": n}
+
+    with open(os.path.join(GOLDEN, "oracle_a_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("wrote fixtures to", GOLDEN)
+
+
+if __name__ == "__main__":
+    main()

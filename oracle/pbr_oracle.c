@@ -630,6 +630,11 @@ static void lut_sample(const OrcShadeInputs* in, int flags, float u, float v, fl
     }
 }
 
+void orc_lut_sample(const uint16_t* lut, int size, float u, float v, float out[2]) {
+    OrcShadeInputs in; memset(&in, 0, sizeof in); in.lut = lut; in.lut_size = size;
+    lut_sample(&in, 0, u, v, out);
+}
+
 static void irradiance_sample(const OrcShadeInputs* in, int flags, v3 d, float out[4]) {
     if (flags & ORC_SHADE_ANALYTIC) {
         float dd[3] = {d.x, d.y, d.z}; orc_env_analytic(dd, out);

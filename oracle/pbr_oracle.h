@@ -107,6 +107,9 @@ typedef struct OrcShadeInputs {
     int            lut_size;
 } OrcShadeInputs;
 
+/* bilinear, clamp-to-edge fetch of an RG16F texture (lighting_pass.glsl:681 BRDF_INTEGRATION_MAP) */
+void   orc_lut_sample(const uint16_t* lut, int size, float u, float v, float out[2]);
+
 /* out_rgba: [H][W][4] fp32 (pre-quantisation); rows [y0,y1), columns [x0,x1) are written. */
 void   orc_shade(const OrcGlobals* g, const OrcShadeInputs* in, int flags,
                  int x0, int x1, int y0, int y1, float* out_rgba);

@@ -1,0 +1,350 @@
+"""Seeded synthetic inputs for the IBL / shade hot path.
+
+The reference's real inputs (shipyard_cranes_track_cube.hdr, MetalRoughSpheres.glb, SunTemple.fbx)
+are absent from the mount, so benchmarks and parity tests use these generators.  Pure numpy; no
+oracle and no GPU code is involved.  Everything is deterministic in (size, seed).
+"""
+import numpy as np
+
+# ---- cube geometry (Vulkan face table quoted in gen_prefiltered_env_map.glsl:12-23) ----------
+
+
+def face_dirs(W, dtype=np.float64):
+    """Unit directions of texel centres, shape [6][W][W][3] (face, row=y, col=x)."""
+    c = (np.arange(W, dtype=dtype) + 0.5) / W
+    u, v = np.meshgrid(c, c, indexing="xy")
+    sc, tc = 2 * (u - 0.5), 2 * (v - 0.5)
+    one = np.ones_like(sc)
+    faces = [
+        (one, -tc, -sc), (-one, -tc, sc), (sc, one, tc), (sc, -one, -tc), (sc, -tc, one), (-sc, -tc, -one),
+    ]
+    d = np.stack([np.stack(f, axis=-1) for f in faces], axis=0)
+    return d / np.linalg.norm(d, axis=-1, keepdims=True)
+
+
+# ---- integer hash noise ----------------------------------------------------------------------
+
+
+def _pcg_hash(x):
+    x = x.astype(np.uint64) & np.uint64(0xFFFFFFFF)
+    x = (x * np.uint64(747796405) + np.uint64(2891336453)) & np.uint64(0xFFFFFFFF)
+    sh = ((x >> np.uint64(28)) + np.uint64(4))
+    w = (((x >> sh) ^ x) * np.uint64(277803737)) & np.uint64(0xFFFFFFFF)
+    return ((w >> np.uint64(22)) ^ w) & np.uint64(0xFFFFFFFF)
+
+
+def _lattice(ix, iy, iz, seed):
+    h = _pcg_hash(ix.astype(np.int64) & 0xFFFFFFFF)
+    h = _pcg_hash(h ^ (iy.astype(np.int64) & 0xFFFFFFFF).astype(np.uint64))
+    h = _pcg_hash(h ^ (iz.astype(np.int64) & 0xFFFFFFFF).astype(np.uint64))
+    h = _pcg_hash(h ^ np.uint64(seed & 0xFFFFFFFF))
+    return h.astype(np.float64) / 4294967296.0
+
+
+def value_noise3(p, seed):
+    """Trilinear value noise on the integer lattice; p[...,3] float64 -> [0,1)."""
+    pf = np.floor(p)
+    f = p - pf
+    f = f * f * (3 - 2 * f)
+    ix, iy, iz = (pf[..., k].astype(np.int64) for k in range(3))
+    out = 0
+    for dx in (0, 1):
+        wx = f[..., 0] if dx else 1 - f[..., 0]
+        for dy in (0, 1):
+            wy = f[..., 1] if dy else 1 - f[..., 1]
+            for dz in (0, 1):
+                wz = f[..., 2] if dz else 1 - f[..., 2]
+                out = out + wx * wy * wz * _lattice(ix + dx, iy + dy, iz + dz, seed)
+    return out
+
+
+# ---- RGBE -------------------------------------------------------------------------------------
+
+
+def rgbe_encode(rgb):
+    """float [...,3] -> uint8 [...,4] (Radiance convention: value = mantissa * 2^(e-136))."""
+    rgb = np.asarray(rgb, dtype=np.float64)
+    m = rgb.max(axis=-1)
+    out = np.zeros(rgb.shape[:-1] + (4,), dtype=np.uint8)
+    ok = m > 1e-32
+    mant, ex = np.frexp(np.where(ok, m, 1.0))        # m = mant * 2^ex, mant in [0.5,1)
+    scale = np.where(ok, mant * 256.0 / np.where(ok, m, 1.0), 0.0)
+    out[..., :3] = np.clip(np.floor(rgb * scale[..., None]), 0, 255).astype(np.uint8)
+    out[..., 3] = np.where(ok, ex + 128, 0).astype(np.uint8)
+    out[~ok] = 0
+    return out
+
+
+def rgbe_decode(rgbe):
+    """uint8 [...,4] -> float32 [...,4] with A = 1, exactly as stbi__hdr_convert does."""
+    rgbe = np.asarray(rgbe, dtype=np.uint8)
+    e = rgbe[..., 3].astype(np.int32)
+    f1 = np.ldexp(np.float32(1.0), e - 136).astype(np.float32)
+    out = np.ones(rgbe.shape[:-1] + (4,), dtype=np.float32)
+    out[..., :3] = rgbe[..., :3].astype(np.float32) * f1[..., None]
+    out[..., :3][e == 0] = 0
+    return out
+
+
+def hdr_file_bytes(rgbe_rows, rle=True):
+    """Encode uint8 [H][W][4] RGBE pixels as a Radiance .hdr file (new-style RLE or flat)."""
+    H, W, _ = rgbe_rows.shape
+    head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n" + f"-Y {H} +X {W}\n".encode()
+    if not rle or W < 8 or W >= 32768:
+        return head + rgbe_rows.tobytes()
+    out = bytearray(head)
+    for y in range(H):
+        out += bytes([2, 2, (W >> 8) & 0xFF, W & 0xFF])
+        for k in range(4):
+            ch = rgbe_rows[y, :, k]
+            i = 0
+            while i < W:
+                # find a run
+                run = 1
+                while i + run < W and run < 127 and ch[i + run] == ch[i]:
+                    run += 1
+                if run >= 4:
+                    out += bytes([128 + run, int(ch[i])])
+                    i += run
+                else:
+                    j = i
+                    while j < W and j - i < 128:
+                        r = 1
+                        while j + r < W and r < 4 and ch[j + r] == ch[j]:
+                            r += 1
+                        if r >= 4:
+                            break
+                        j += 1
+                    n = max(1, j - i)
+                    out += bytes([n]) + ch[i:i + n].tobytes()
+                    i += n
+    return bytes(out)
+
+
+# ---- environment ------------------------------------------------------------------------------
+
+SUN_DIR = np.array([0.35, 0.55, 0.757], dtype=np.float64)
+SUN_DIR /= np.linalg.norm(SUN_DIR)
+
+
+def synth_env(W, seed=0x5EED0001, rgbe_roundtrip=True, chunk_rows=256):
+    """Procedural HDR cube [6][W][W][4] float32: sky gradient + sun disc (peak 5e4) + horizon band
+    + value noise, round-tripped through RGBE so the values are what stbi_loadf would return."""
+    out = np.empty((6, W, W, 4), dtype=np.float32)
+    c = (np.arange(W, dtype=np.float64) + 0.5) / W
+    for f in range(6):
+        for y0 in range(0, W, chunk_rows):
+            y1 = min(W, y0 + chunk_rows)
+            u, v = np.meshgrid(c, c[y0:y1], indexing="xy")
+            sc, tc = 2 * (u - 0.5), 2 * (v - 0.5)
+            one = np.ones_like(sc)
+            comps = [(one, -tc, -sc), (-one, -tc, sc), (sc, one, tc), (sc, -one, -tc), (sc, -tc, one), (-sc, -tc, -one)][f]
+            d = np.stack(comps, axis=-1)
+            d /= np.linalg.norm(d, axis=-1, keepdims=True)
+            up = d[..., 2]
+            t = np.clip(up * 0.5 + 0.5, 0, 1)
+            sky = np.stack([0.25 + 0.5 * t, 0.35 + 0.65 * t, 0.55 + 0.95 * t], axis=-1)
+            ground = np.stack([0.18 + 0 * t, 0.15 + 0 * t, 0.12 + 0 * t], axis=-1)
+            col = np.where((up > 0)[..., None], sky, ground)
+            band = np.exp(-(up / 0.06) ** 2)
+            col = col + band[..., None] * np.array([0.9, 0.7, 0.45])
+            n1 = value_noise3(d * 6.0 + 17.0, seed)
+            n2 = value_noise3(d * 23.0 + 5.0, seed ^ 0x9E3779B9)
+            col = col * (0.6 + 0.5 * n1 + 0.3 * n2)[..., None]
+            cs = d @ SUN_DIR
+            ang = np.arccos(np.clip(cs, -1, 1))
+            sun = 5.0e4 * np.exp(-(ang / 0.012) ** 4) + 40.0 * np.exp(-(ang / 0.08) ** 2)
+            col = col + sun[..., None] * np.array([1.0, 0.92, 0.8])
+            if rgbe_roundtrip:
+                out[f, y0:y1] = rgbe_decode(rgbe_encode(col))
+            else:
+                out[f, y0:y1, :, :3] = col.astype(np.float32)
+                out[f, y0:y1, :, 3] = 1.0
+    return out
+
+
+def env_to_hdr_strip(env, rle=True):
+    """[6][W][W][4] float cube -> bytes of a W x 6W vertical-strip .hdr (asset_import.cpp:17-27 layout)."""
+    W = env.shape[1]
+    rows = rgbe_encode(env[..., :3].reshape(6 * W, W, 3))
+    return hdr_file_bytes(rows, rle=rle)
+
+
+# ---- camera / Globals (numpy float64 model used only to build synthetic G-buffers) -------------
+
+
+def perspective_lh_zo(fov_deg, aspect, near, far):
+    """HMM_Perspective_LH_ZO as used by utils/camera.h:112 (column-major list of columns)."""
+    cot = 1.0 / np.tan(np.deg2rad(fov_deg) / 2.0)
+    m = np.zeros((4, 4))          # m[col][row]
+    m[0][0] = cot / aspect
+    m[1][1] = cot
+    m[2][3] = 1.0
+    m[2][2] = -(far / (near - far))
+    m[3][2] = (near * far) / (near - far)
+    return m
+
+
+def quat_axis_angle(axis, angle):
+    axis = np.asarray(axis, dtype=np.float64)
+    axis = axis / np.linalg.norm(axis)
+    s = np.sin(angle / 2)
+    return np.array([axis[0] * s, axis[1] * s, axis[2] * s, np.cos(angle / 2)])
+
+
+def quat_to_mat3(q):
+    x, y, z, w = q
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+def camera_matrices(pos, ori_q, fov_deg=75.0, aspect=16.0 / 9.0, near=0.02, far=1.0e4):
+    """Row-major 4x4 (math convention, M @ column-vector) float64 matrices of the camera model."""
+    R = quat_to_mat3(ori_q)
+    wfv = np.eye(4)
+    wfv[:3, :3] = R
+    wfv[:3, 3] = pos
+    vfw = np.linalg.inv(wfv)
+    cfv = perspective_lh_zo(fov_deg, aspect, near, far).T    # to row-major math convention
+    cfw = cfv @ vfw
+    return dict(world_from_view=wfv, view_from_world=vfw, clip_from_view=cfv, clip_from_world=cfw,
+                world_from_clip=np.linalg.inv(cfw), view_from_clip=np.linalg.inv(cfv))
+
+
+DEFAULT_ORI = quat_axis_angle((1, 0, 0), -np.pi / 2)     # utils/camera.h:45
+
+
+def _encode_unorm8(x):
+    return np.clip(np.floor(x * 255.0 + 0.5), 0, 255).astype(np.uint8)
+
+
+PALETTE = np.array([[0.95, 0.64, 0.54], [0.91, 0.92, 0.92], [1.0, 0.77, 0.34], [0.56, 0.57, 0.58],
+                    [0.8, 0.1, 0.1], [0.1, 0.5, 0.8], [0.2, 0.7, 0.3]])
+
+
+def synth_gbuffer_spheres(width=1920, height=1080, cam_pos=(0.0, -9.0, 0.0), ori_q=None):
+    """C3: 7x7 grid of unit-radius-0.55 spheres in the XZ plane at y=0, camera at (0,-9,0) facing +Y.
+    metallic = row/6, roughness = col/6.  Returns dict of G-buffer arrays + camera matrices."""
+    ori_q = DEFAULT_ORI if ori_q is None else ori_q
+    cam = camera_matrices(np.asarray(cam_pos, dtype=np.float64), ori_q, aspect=width / height)
+    xs = (np.arange(width) + 0.5) / width * 2 - 1
+    ys = (np.arange(height) + 0.5) / height * 2 - 1
+    X, Y = np.meshgrid(xs, ys, indexing="xy")
+    wfc = cam["world_from_clip"]
+
+    def unproject(z):
+        p = np.stack([X, Y, np.full_like(X, z), np.ones_like(X)], axis=-1) @ wfc.T
+        return p[..., :3] / p[..., 3:4]
+
+    o = np.asarray(cam_pos, dtype=np.float64)
+    far_pt = unproject(0.5)
+    rd = far_pt - o
+    rd /= np.linalg.norm(rd, axis=-1, keepdims=True)
+    base = np.zeros((height, width, 4), np.uint8)
+    nrm = np.zeros((height, width, 4), np.uint8)
+    orm = np.zeros((height, width, 4), np.uint8)
+    emi = np.zeros((height, width, 4), np.uint8)
+    depth = np.ones((height, width), np.float32)
+    tbest = np.full((height, width), np.inf)
+    rad = 0.55
+    for row in range(7):
+        for col in range(7):
+            c = np.array([(col - 3) * 1.3, 0.0, (3 - row) * 1.3])
+            oc = o - c
+            b = rd @ oc
+            disc = b * b - (oc @ oc - rad * rad)
+            hit = disc > 0
+            t = -b - np.sqrt(np.where(hit, disc, 0))
+            hit &= (t > 0) & (t < tbest)
+            if not hit.any():
+                continue
+            P = o + rd * t[..., None]
+            N = (P - c) / rad
+            tbest = np.where(hit, t, tbest)
+            clip = np.concatenate([P, np.ones_like(P[..., :1])], axis=-1) @ cam["clip_from_world"].T
+            z = (clip[..., 2] / clip[..., 3]).astype(np.float32)
+            depth[hit] = z[hit]
+            nrm[hit, :3] = _encode_unorm8(N * 0.5 + 0.5)[hit]
+            nrm[hit, 3] = 255
+            base[hit, :3] = _encode_unorm8(PALETTE[(row + col) % 7])
+            base[hit, 3] = 255
+            orm[hit] = _encode_unorm8(np.array([1.0, max(col / 6.0, 0.0), row / 6.0, 1.0]))
+    return dict(base=base, normal=nrm, orm=orm, emissive=emi, depth=depth, camera=cam,
+                cam_pos=np.asarray(cam_pos, np.float64), ori_q=ori_q)
+
+
+def synth_gbuffer_temple(width=7680, height=4320, seed=0x5EED0005, cam_pos=(0.0, -30.0, 6.0), ori_q=None):
+    """C5: ground plane z=0 + ring of 32 columns + dome, per-pixel material from value noise,
+    2% emissive pixels.  Analytic ray casting in float64, evaluated row-block-wise."""
+    ori_q = DEFAULT_ORI if ori_q is None else ori_q
+    cam = camera_matrices(np.asarray(cam_pos, dtype=np.float64), ori_q, aspect=width / height)
+    base = np.zeros((height, width, 4), np.uint8)
+    nrm = np.zeros((height, width, 4), np.uint8)
+    orm = np.zeros((height, width, 4), np.uint8)
+    emi = np.zeros((height, width, 4), np.uint8)
+    depth = np.ones((height, width), np.float32)
+    o = np.asarray(cam_pos, dtype=np.float64)
+    wfc = cam["world_from_clip"]
+    xs = (np.arange(width) + 0.5) / width * 2 - 1
+    col_ang = np.arange(32) * (2 * np.pi / 32)
+    col_c = np.stack([18 * np.cos(col_ang), 18 * np.sin(col_ang)], axis=-1)
+    blk = 135
+    for y0 in range(0, height, blk):
+        y1 = min(height, y0 + blk)
+        ys = (np.arange(y0, y1) + 0.5) / height * 2 - 1
+        X, Y = np.meshgrid(xs, ys, indexing="xy")
+        p = np.stack([X, Y, np.full_like(X, 0.5), np.ones_like(X)], axis=-1) @ wfc.T
+        rd = p[..., :3] / p[..., 3:4] - o
+        rd /= np.linalg.norm(rd, axis=-1, keepdims=True)
+        tb = np.full(X.shape, np.inf)
+        N = np.zeros(X.shape + (3,))
+        # ground
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = -o[2] / rd[..., 2]
+        hit = (rd[..., 2] < 0) & (t > 0) & (t < 400)
+        tb = np.where(hit, t, tb)
+        N[hit] = (0, 0, 1)
+        # dome (sphere radius 60 centred at origin, seen from inside, only z>0 part)
+        b = rd @ o
+        disc = b * b - (o @ o - 60.0 ** 2)
+        t = -b + np.sqrt(np.maximum(disc, 0))
+        P = o + rd * t[..., None]
+        hit = (disc > 0) & (t > 0) & (P[..., 2] > 0) & (t < tb)
+        tb = np.where(hit, t, tb)
+        N = np.where(hit[..., None], -P / 60.0, N)
+        # columns (vertical cylinders radius 1.2, height 14)
+        for c in col_c:
+            oc = o[:2] - c
+            a = (rd[..., :2] ** 2).sum(-1)
+            bb = rd[..., :2] @ oc
+            cc = oc @ oc - 1.2 ** 2
+            disc = bb * bb - a * cc
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = (-bb - np.sqrt(np.maximum(disc, 0))) / a
+            P = o + rd * t[..., None]
+            hit = (disc > 0) & (t > 0) & (t < tb) & (P[..., 2] > 0) & (P[..., 2] < 14)
+            tb = np.where(hit, t, tb)
+            n = np.concatenate([(P[..., :2] - c) / 1.2, np.zeros_like(P[..., :1])], axis=-1)
+            N = np.where(hit[..., None], n, N)
+        hit = np.isfinite(tb)
+        P = o + rd * np.where(hit, tb, 0)[..., None]
+        clip = np.concatenate([P, np.ones_like(P[..., :1])], axis=-1) @ cam["clip_from_world"].T
+        z = (clip[..., 2] / clip[..., 3]).astype(np.float32)
+        depth[y0:y1] = np.where(hit, z, 1.0)
+        n1 = value_noise3(P * 0.7 + 3.0, seed)
+        n2 = value_noise3(P * 2.9 + 11.0, seed ^ 0xABCDEF)
+        n3 = value_noise3(P * 0.23 + 7.0, seed ^ 0x13579B)
+        bc = np.stack([0.35 + 0.6 * n1, 0.3 + 0.55 * n2, 0.25 + 0.5 * n3], axis=-1)
+        base[y0:y1, :, :3] = np.where(hit[..., None], _encode_unorm8(bc), 0)
+        base[y0:y1, :, 3] = np.where(hit, 255, 0)
+        nrm[y0:y1, :, :3] = np.where(hit[..., None], _encode_unorm8(N * 0.5 + 0.5), 0)
+        nrm[y0:y1, :, 3] = np.where(hit, 255, 0)
+        o3 = np.stack([np.ones_like(n1), 0.08 + 0.9 * n2, (n3 > 0.6).astype(np.float64), np.ones_like(n1)], axis=-1)
+        orm[y0:y1] = np.where(hit[..., None], _encode_unorm8(o3), 0)
+        em = (n1 * 7919.0 % 1.0 < 0.02) & hit
+        emi[y0:y1, :, :3] = np.where(em[..., None], _encode_unorm8(np.stack([n2, 0.5 * n3, 0.2 * n1], axis=-1)), 0)
+    return dict(base=base, normal=nrm, orm=orm, emissive=emi, depth=depth, camera=cam,
+                cam_pos=np.asarray(cam_pos, np.float64), ori_q=ori_q)
