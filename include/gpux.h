@@ -1,0 +1,57 @@
+/*
+ * gpux.h -- extensions of the HIP backend beyond the reference's GPU_* API (new names only; nothing
+ * in gpu_hip.h changes meaning).  They exist for what the reference cannot express:
+ * multi-GPU sharding (dispatch of a (face,row) sub-range, device selection), reading back mips
+ * other than 0 (the reference's GPU_OpCopyTextureToBuffer is mip-0 only, gpu_vulkan.c:2945-2951),
+ * parameterised sizes/sample counts (literals inside the reference shaders), per-op HIP-event
+ * timing, and handing device pointers to a communication library (RCCL).
+ */
+#ifndef GPUX_H
+#define GPUX_H
+
+#include "gpu_hip.h"
+
+/* ---- device / errors ---- */
+GPU_API void GPUX_SetDevice(int hip_device_index);        /* call before GPU_Init; default: $LOCAL_RANK or 0 */
+GPU_API int  GPUX_GetDevice(void);
+typedef void (*GPUX_ErrorHandler)(const char* message, void* user);
+/* With a handler installed, a failing GPU_* call reports and returns (NULL / no-op) instead of aborting. */
+GPU_API void GPUX_SetErrorHandler(GPUX_ErrorHandler handler, void* user);
+GPU_API const char* GPUX_BackendName(void);               /* "hip-gfx950" */
+
+/* ---- push-constant block understood by the IBL kernels when size == sizeof(GPUX_IBLConstants).
+ * A 4-byte block keeps the reference meaning (int mip_level; gen_prefiltered_env_map.glsl:99-101):
+ * roughness = {0,.03,.15,.4,.6}[mip] (mips >= 5: min(1, .6 + .08*(mip-4)), an extension),
+ * source LOD = 1 for mip 0 else 3 + mip (clamped to the env chain), 8192 samples. ---- */
+typedef struct GPUX_IBLConstants {
+    int32_t mip_level;        /* prefilter: which branch (0 = copy, else Monte-Carlo) */
+    float   roughness;        /* prefilter MC roughness */
+    float   src_lod;          /* integer-valued source LOD */
+    int32_t sample_count;     /* 0 = shader default (8192 prefilter / 1024 irradiance / 4096 LUT) */
+} GPUX_IBLConstants;
+
+/* ---- sub-range dispatch: like GPU_OpDispatch over the bound OUTPUT image, restricted to faces
+ * [face0,face1) and rows [row0,row1) (rows of the LUT for gen_brdf_integration_map). ---- */
+GPU_API void GPUX_OpDispatchRows(GPU_Graph* graph, uint32_t face0, uint32_t face1, uint32_t row0, uint32_t row1);
+
+/* ---- shade pass controls ---- */
+enum { GPUX_Shade_IBL = 1 << 0, GPUX_Shade_LightShafts = 1 << 1 };
+GPU_API void GPUX_SetShadeFlags(GPU_GraphicsPipeline* pipeline, int flags);    /* default GPUX_Shade_IBL */
+/* full-screen draw restricted to rows [row0,row1) (screen-band sharding) */
+GPU_API void GPUX_OpDrawRows(GPU_Graph* graph, uint32_t row0, uint32_t row1);
+
+/* ---- transfers the reference API lacks ---- */
+GPU_API void GPUX_OpCopyTextureMipToBuffer(GPU_Graph* graph, GPU_Texture* src, uint32_t mip_level, GPU_Buffer* dst, uint32_t dst_offset);
+GPU_API void GPUX_OpCopyBufferToTextureMip(GPU_Graph* graph, GPU_Buffer* src, uint32_t src_offset, GPU_Texture* dst, uint32_t mip_level);
+GPU_API uint64_t GPUX_TextureMipBytes(const GPU_Texture* texture, uint32_t mip_level);   /* all layers of one mip */
+GPU_API void* GPUX_TextureDevicePtr(GPU_Texture* texture, uint32_t mip_level);            /* for RCCL / interop */
+GPU_API void* GPUX_BufferDevicePtr(GPU_Buffer* buffer);
+GPU_API void* GPUX_GraphStream(GPU_Graph* graph);                                         /* hipStream_t */
+
+/* ---- per-op timing with HIP events on the graph's own stream ---- */
+GPU_API void GPUX_EnableOpTiming(int enable);
+GPU_API uint32_t GPUX_GraphTimedOpCount(GPU_Graph* graph);          /* ops of the last waited submission */
+GPU_API const char* GPUX_GraphTimedOpName(GPU_Graph* graph, uint32_t index);
+GPU_API float GPUX_GraphTimedOpMs(GPU_Graph* graph, uint32_t index);
+
+#endif

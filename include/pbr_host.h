@@ -1,0 +1,105 @@
+/*
+ * pbr_host.h -- C host layer above the GPU_* boundary: the reference renderer's own call
+ * sequences for the IBL precompute and the lighting pass, restated in C11 against gpu_hip.h so
+ * that they run headless (no window, no assimp, no glslang).  Every function cites the reference
+ * code whose GPU_* call sequence it reproduces; a reference maintainer could delete these and
+ * keep calling GPU_* from render.cpp unchanged.
+ */
+#ifndef PBR_HOST_H
+#define PBR_HOST_H
+
+#include "gpux.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- A1: Radiance .hdr (RGBE) decode, what stbi_loadf(..., 4) returns for asset_import.cpp:19
+ * (third_party/stb_image.h:7130-7286): flat or new-RLE scanlines, rgb = mantissa * 2^(e-136),
+ * alpha = 1, e == 0 -> 0.  Returns malloc'ed float RGBA [h][w][4] or NULL (reason in *err). */
+float* PBR_DecodeHDR(const void* bytes, size_t size, int* w, int* h, const char** err);
+
+/* asset_import.cpp:17-27: vertical strip of 6 square faces (height == 6*width) -> RGBA32F cubemap
+ * with a full mip chain (GPU_MakeTexture uploads and generates the mips before returning). */
+GPU_Texture* PBR_MakeTextureFromHDRIMemory(const void* bytes, size_t size);
+GPU_Texture* PBR_MakeTextureFromHDRIFile(const char* filepath);
+
+/* ---- IBL precompute, render.cpp:505-619 ---- */
+typedef struct PBR_IBLMaps {
+    GPU_Texture* irradiance_map;        /* RGBA32F cube, render.cpp:794 (32x32) */
+    GPU_Texture* brdf_lut;              /* RG16F 2D,    render.cpp:795 (256x256) */
+    GPU_Texture* tex_specular_env_map;  /* RGBA32F cube + mips, render.cpp:796 (256x256) */
+} PBR_IBLMaps;
+
+/* render.cpp:794-796 with the sizes as parameters (reference: 32, 256, 256) */
+void PBR_MakeIBLMaps(PBR_IBLMaps* maps, uint32_t irradiance_size, uint32_t lut_size, uint32_t specular_size);
+void PBR_DestroyIBLMaps(PBR_IBLMaps* maps);
+
+/* One work unit of the precompute = rows [row0,row1) of faces [face0,face1) of one output level. */
+typedef enum PBR_UnitKind { PBR_Unit_Prefilter = 0, PBR_Unit_Irradiance = 1, PBR_Unit_BrdfLut = 2 } PBR_UnitKind;
+typedef struct PBR_WorkUnit {
+    uint32_t kind;                      /* PBR_UnitKind */
+    uint32_t mip;                       /* prefilter output mip */
+    uint32_t face0, face1, row0, row1;
+    double   cost;                      /* texels * samples-per-texel (1 for the copy mip) */
+} PBR_WorkUnit;
+
+void PBR_GenIrradianceMap(GPU_Texture* tex_env_cube, GPU_Texture* irradiance_map);           /* render.cpp:505-540 */
+/* render.cpp:542-589; min_size = 16 reproduces the reference's `if (size < 16) break;`, 1 runs the whole chain */
+void PBR_GenPrefilteredEnvMap(GPU_Texture* tex_env_cube, GPU_Texture* tex_specular_env_map, uint32_t min_size);
+void PBR_GenBRDFIntegrationMap(GPU_Texture* brdf_lut);                                       /* render.cpp:591-619 */
+/* Records (does not submit) the dispatches of an explicit unit list into `graph`: the sharded form of the above.
+ * `arena` receives the per-unit descriptor sets (caller resets it after GPU_GraphWait). */
+typedef struct PBR_IBLPipelines PBR_IBLPipelines;
+PBR_IBLPipelines* PBR_MakeIBLPipelines(void);
+void PBR_DestroyIBLPipelines(PBR_IBLPipelines* p);
+void PBR_RecordUnits(PBR_IBLPipelines* p, GPU_Graph* graph, GPU_DescriptorArena* arena, GPU_Texture* tex_env_cube,
+                     const PBR_IBLMaps* maps, const PBR_WorkUnit* units, uint32_t unit_count);
+
+/* Enumerates the precompute's work units (prefilter mips down to min_size, optionally irradiance) cut
+ * into row tiles, and assigns them to `world` ranks by cost (greedy longest-first).
+ * Returns the number of units written to out (<= capacity) for `rank`; rank < 0 lists all units. */
+uint32_t PBR_PartitionIBL(uint32_t specular_size, uint32_t min_size, uint32_t irradiance_size, uint32_t env_size,
+                          int world, int rank, PBR_WorkUnit* out, uint32_t capacity);
+
+/* ---- camera + Globals: utils/camera.h:95-120 and render.cpp:962-991 ---- */
+typedef struct PBR_Globals {            /* RendererGlobalsBuffer, render.h:122-136; column-major mat4 */
+    float clip_space_from_world[16];
+    float clip_space_from_view[16];
+    float world_space_from_clip[16];
+    float view_space_from_clip[16];
+    float view_space_from_world[16];
+    float world_space_from_view[16];
+    float sun_space_from_world[16];
+    float old_clip_space_from_world[16];
+    float sun_direction[4];
+    float camera_pos[3];
+    float frame_idx_mod_59;
+    float lightgrid_scale;
+    uint32_t visualize_lightgrid;
+} PBR_Globals;
+
+/* ori_xyzw == NULL -> the reference's default orientation (faces +Y, utils/camera.h:45). */
+void PBR_FillGlobals(PBR_Globals* out, const float pos[3], const float ori_xyzw[4], float fov_degrees, float aspect,
+                     float z_near, float z_far, float sun_angle_x_deg, float sun_angle_y_deg, uint32_t frame_idx);
+
+/* ---- lighting pass: layout/descriptor set of render.cpp:829-871, pass of :716-723, draw of :1119-1127 ---- */
+typedef struct PBR_GBuffer {
+    GPU_Texture* base_color; GPU_Texture* normal; GPU_Texture* orm; GPU_Texture* emissive; GPU_Texture* depth;   /* render.cpp:680-687 */
+    GPU_Texture* lighting_result;                                                                                /* render.cpp:693 */
+} PBR_GBuffer;
+void PBR_MakeGBuffer(PBR_GBuffer* gb, uint32_t width, uint32_t height, GPU_Format result_format);
+void PBR_DestroyGBuffer(PBR_GBuffer* gb);
+
+typedef struct PBR_LightingPass PBR_LightingPass;
+PBR_LightingPass* PBR_MakeLightingPass(const PBR_GBuffer* gb, const PBR_IBLMaps* maps, uint32_t width, uint32_t height);
+void PBR_DestroyLightingPass(PBR_LightingPass* lp);
+GPU_Buffer* PBR_LightingGlobalsBuffer(PBR_LightingPass* lp);           /* persistently mapped (render.cpp:675) */
+GPU_GraphicsPipeline* PBR_LightingPipeline(PBR_LightingPass* lp);
+/* render.cpp:977-991 + 1119-1127: copies globals into the mapped buffer and records the pass; rows [row0,row1), row1 == 0 -> all */
+void PBR_RecordLightingPass(PBR_LightingPass* lp, GPU_Graph* graph, const PBR_Globals* globals, uint32_t row0, uint32_t row1);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,118 @@
+/*
+ * pbr_kernels.h -- low-level C ABI of the gfx950 kernels (device pointers + stream in, status out).
+ *
+ * This is the layer *under* the GPU_* boundary of include/gpu_hip.h: every entry point takes
+ * plain device pointers and sizes, launches asynchronously on `stream` (a hipStream_t passed as
+ * void*) and returns 0 or a negative PBRK_E_* code after validating shapes on the host (no launch
+ * happens when validation fails).  Each entry names the reference code it replaces.
+ *
+ * Memory layouts (all tightly packed, little endian):
+ *   cube level        float4 [6][n][n]                (RGBA32F, face order +X,-X,+Y,-Y,+Z,-Z)
+ *   cube pyramid      levels 0..L-1 back to back, level l has n_l = max(1, W >> l)
+ *   bordered level    float4 [6][n+2][n+2]            (apron = adjacent faces' edge texels)
+ *   bordered pyramid  bordered levels back to back
+ *   G-buffer planes   uchar4 [H][W] x4, float [H][W]  (base colour, normal, ORM, emissive, depth)
+ *   lit frame         half4 [H][W] or float4 [H][W]
+ */
+#ifndef PBR_KERNELS_H
+#define PBR_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    PBRK_OK = 0,
+    PBRK_E_ARG = -1,        /* null pointer / non-positive size / bad range */
+    PBRK_E_FORMAT = -2,     /* unsupported pixel format */
+    PBRK_E_LAUNCH = -3      /* hipGetLastError() != hipSuccess after the launch */
+};
+
+enum {                      /* output formats understood by the kernels */
+    PBRK_FMT_RG16F = 1,
+    PBRK_FMT_RG32F = 2,
+    PBRK_FMT_RGBA16F = 3,
+    PBRK_FMT_RGBA32F = 4
+};
+
+enum {                      /* shade flags (reference lighting_pass.glsl sub-blocks) */
+    PBRK_SHADE_IBL = 1 << 0,     /* ambient = irradiance(N); spec = prefiltered(R, rough*4)  (:690, :699) */
+    PBRK_SHADE_SHAFTS = 1 << 1   /* light-shaft loop with visibility == 1 (:622-651) */
+};
+
+/* sizes / offsets of the pyramid layouts, in float4 texels */
+size_t pbrk_level_offset(int W, int level);
+size_t pbrk_pyramid_texels(int W, int levels);
+size_t pbrk_bordered_level_offset(int W, int level);
+size_t pbrk_bordered_pyramid_texels(int W, int levels);
+int    pbrk_mip_count(int w, int h);                    /* src/gpu/gpu_vulkan.c:1344-1351 */
+
+/* ---- host-side tables (libm on the host, so CPU and GPU agree bit-for-bit on directions/weights) -----
+ * angles[i] = (cos pitch_i, sin pitch_i, cos yaw_i, sin yaw_i), the Fibonacci hemisphere of
+ * gen_prefiltered_env_map.glsl:125-128 / gen_irradiance_map.glsl:85-88 / gen_brdf_integration_map.glsl:171-174 */
+void   pbrk_host_sample_angles(int nsamples, float* angles4);
+/* Prefilter table (gen_prefiltered_env_map.glsl:122-143): entries (lx, ly, lz, w) for the samples
+ * whose weight w = D_i*cos(pitch_i)*dw is non-zero, in index order.  Returns the entry count;
+ * *alpha receives the texel-independent alpha channel sum_i(w_i)/PI evaluated in shader order. */
+int    pbrk_host_prefilter_table(int nsamples, float roughness, float* table4, float* alpha);
+/* Irradiance table (gen_irradiance_map.glsl:84-96): entries (lx, ly, lz, cos pitch_i). */
+int    pbrk_host_irradiance_table(int nsamples, float* table4);
+
+/* ---- K2: mip chain, replaces GPU_OpGenerateMipmaps' per-(level,face) linear blits
+ *      (src/gpu/gpu_vulkan.c:1458-1483, :2786-2826): level l = 2x2 box mean of level l-1, per face. */
+int pbrk_mip_chain(void* pyramid, int W, int levels, void* stream);
+/* one exact 2:1 linear blit (GPU_OpBlit, gpu_vulkan.c:2786-2826) of `nlayers` square RGBA32F layers of size ns */
+int pbrk_box_downsample(const void* src, int ns, void* dst, int nlayers, void* stream);
+
+/* ---- border build: pyramid -> bordered pyramid (seamless-cube apron; sampler state of
+ *      src/gpu/gpu_vulkan.c:613-634 applied to a cube view). */
+int pbrk_border_build(const void* pyramid, void* bordered, int W, int levels, void* stream);
+
+/* ---- K1: split-sum BRDF LUT (shaders/gen_brdf_integration_map.glsl:142-210).
+ * angles4: device copy of pbrk_host_sample_angles(nsamples); view_cs: device float2[size] with
+ * (cos, sin) of acos((x+.5)/size) computed on the host.  Rows [y0,y1) are written. */
+int pbrk_brdf_lut(void* out, int out_format, int size, int nsamples, const void* angles4,
+                  const void* view_cs, int y0, int y1, void* stream);
+
+/* ---- K4a: prefilter mip 0 = bilinear copy of one env level (gen_prefiltered_env_map.glsl:112-114).
+ * src_bordered_level: bordered level of size n_src.  out: cube level [6][out_size][out_size]. */
+int pbrk_prefilter_copy(const void* src_bordered_level, int n_src, void* out, int out_size,
+                        int face0, int face1, int y0, int y1, void* stream);
+
+/* ---- K4b / K3: Monte-Carlo hemisphere filter of one output level.
+ * out.rgb = (sum_i w_i * bilinear(src, frame(texel) * l_i)) / divisor ; out.a = alpha.
+ * Prefilter (gen_prefiltered_env_map.glsl:115-146): table from pbrk_host_prefilter_table, divisor PI.
+ * Irradiance (gen_irradiance_map.glsl:81-97): table from pbrk_host_irradiance_table, divisor N, alpha 0. */
+int pbrk_mc_filter(const void* src_bordered_level, int n_src, const void* table4, int n_entries,
+                   float divisor, float alpha, void* out, int out_size,
+                   int face0, int face1, int y0, int y1, void* stream);
+
+/* ---- K5: deferred shade pass (shaders/lighting_pass.glsl:432-716, in-scope sub-blocks). */
+typedef struct PbrkShadeArgs {
+    int width, height;
+    int x0, x1, y0, y1;                 /* pixel rectangle to shade */
+    const void* base_color;             /* uchar4 [H][W] */
+    const void* normal;
+    const void* orm;
+    const void* emissive;
+    const void* depth;                  /* float [H][W] */
+    const void* irradiance_bordered;    /* bordered level, size irradiance_size (IBL mode) */
+    int irradiance_size;
+    const void* prefiltered_bordered;   /* bordered pyramid of the prefiltered cube */
+    int prefiltered_size, prefiltered_levels;
+    const void* lut;                    /* half2 [S][S] */
+    int lut_size;
+    void* out;                          /* half4 or float4 [H][W] */
+    int out_format;                     /* PBRK_FMT_RGBA16F / PBRK_FMT_RGBA32F */
+    int flags;                          /* PBRK_SHADE_* */
+    float globals[138];                 /* RendererGlobalsBuffer, render.h:122-136 (552 bytes) */
+} PbrkShadeArgs;
+int pbrk_shade(const PbrkShadeArgs* args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,236 @@
+"""GPU parity tests: the HIP path, driven through the C ABI (GPU_* / PBR_* in libgpu_hip.so), against the
+CPU oracle and the committed Oracle-A fixtures.  Tolerance from BASELINE.json north_star: 1e-4 relative."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4
+
+
+def rel_err(a, b, floor=1e-6):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), floor)).max())
+
+
+def rmse_rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)) / max(np.sqrt(np.mean(b ** 2)), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def env64(gpu):
+    import pbrhip
+    from pbrhip import synth
+    env = synth.synth_env(64, seed=0x5EED00AA)
+    tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, 64, 64, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+    yield env, tex
+    gpu.GPU_DestroyTexture(tex)
+
+
+def test_mip_chain_bit_exact(gpu, env64):
+    """K2 vs oracle (gpu_vulkan.c:1458-1483 semantics): every level of the pyramid, bit for bit."""
+    import pbrhip, pbr_oracle as O
+    env, tex = env64
+    pyr = O.build_pyramid(env)
+    assert tex.contents.mip_level_count == 7
+    for m in range(7):
+        got = pbrhip.read_mip(tex, m)
+        want = O.pyramid_level(pyr, 64, m)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"level {m}"
+
+
+def test_brdf_lut_fp32_and_fp16(gpu, golden_dir):
+    """K1 vs the Oracle-A LUT (reference shader text executed on the CPU)."""
+    import pbrhip, pbr_oracle as O
+    want = np.load(os.path.join(golden_dir, "oracle_a_lut256.npy"))
+    t32 = pbrhip.make_texture(pbrhip.Format_RG32F, 256, 256, pbrhip.TextureFlag_StorageImage)
+    gpu.PBR_GenBRDFIntegrationMap(t32)
+    got = pbrhip.read_mip(t32, 0)
+    gpu.GPU_DestroyTexture(t32)
+    assert not np.isnan(got).any()
+    assert rmse_rel(got, want) < REL
+    # per-texel: relative to the texel's own magnitude, with a floor for the near-zero bias entries
+    err = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-3)
+    assert err.max() < REL, f"max rel {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+    # RG16F store (render.cpp:795): bits equal to RTE(oracle) or one ulp away
+    t16 = pbrhip.make_texture(pbrhip.Format_RG16F, 256, 256, pbrhip.TextureFlag_StorageImage)
+    gpu.PBR_GenBRDFIntegrationMap(t16)
+    h = pbrhip.read_mip(t16, 0).view(np.uint16).astype(np.int32)
+    gpu.GPU_DestroyTexture(t16)
+    ref = want.astype(np.float16).view(np.uint16).astype(np.int32)
+    assert np.abs(h - ref).max() <= 1
+    assert (h != ref).mean() < 0.01
+
+
+def _run_prefilter(gpu, env_tex, out_size, min_size):
+    import pbrhip
+    spec = pbrhip.make_texture(pbrhip.Format_RGBA32F, out_size, out_size,
+                               pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps | pbrhip.TextureFlag_StorageImage)
+    gpu.PBR_GenPrefilteredEnvMap(env_tex, spec, min_size)
+    return spec
+
+
+def test_prefilter_env64_vs_oracle_a(gpu, env64, golden_dir):
+    """K4a/K4b on the textured W=64 environment vs Oracle-A fixtures (mips 0-2 of a 64^2 cube)."""
+    import pbrhip
+    env, tex = env64
+    spec = _run_prefilter(gpu, tex, 64, 16)
+    for m in (0, 1, 2):
+        want = np.load(os.path.join(golden_dir, f"oracle_a_prefilter_env64_out64_mip{m}.npy"))
+        got = pbrhip.read_mip(spec, m)
+        assert got.shape == want.shape
+        assert rmse_rel(got, want) < REL, f"mip {m}"
+        assert rel_err(got, want, floor=1e-3) < REL, f"mip {m}: {rel_err(got, want, floor=1e-3)}"
+        if m > 0:   # alpha channel = sum of weights, texel independent (shader order on the host)
+            assert np.all(got[..., 3] == got[0, 0, 0, 3])
+            assert got[0, 0, 0, 3] == want[0, 0, 0, 3]
+    gpu.GPU_DestroyTexture(spec)
+
+
+def test_prefilter_full_chain_vs_oracle(gpu, env64):
+    """Whole chain down to 1x1 (mips >= 5 use the documented extension rule), vs Oracle-B."""
+    import pbrhip, pbr_oracle as O
+    env, tex = env64
+    pyr = O.build_pyramid(env)
+    spec = _run_prefilter(gpu, tex, 32, 1)
+    for m in range(6):
+        got = pbrhip.read_mip(spec, m)
+        want = O.prefilter_mip(pyr, 64, 32, m)
+        assert rel_err(got, want, floor=1e-3) < REL, f"mip {m}: {rel_err(got, want, floor=1e-3)}"
+    gpu.GPU_DestroyTexture(spec)
+
+
+def test_irradiance_env256_vs_oracle_a(gpu, golden_dir):
+    """K3 (32^2, 1024 samples, env LOD 6 of a 256^2 cube) vs the Oracle-A fixture."""
+    import pbrhip
+    from pbrhip import synth
+    env = synth.synth_env(256, seed=0x5EED00AB)
+    tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, 256, 256, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+    irr = pbrhip.make_texture(pbrhip.Format_RGBA32F, 32, 32, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_StorageImage)
+    gpu.PBR_GenIrradianceMap(tex, irr)
+    got = pbrhip.read_mip(irr, 0)
+    want = np.load(os.path.join(golden_dir, "oracle_a_irradiance_env256.npy"))
+    assert rmse_rel(got, want) < REL
+    assert rel_err(got[..., :3], want[..., :3], floor=1e-3) < REL
+    assert np.all(got[..., 3] == 0)
+    gpu.GPU_DestroyTexture(irr); gpu.GPU_DestroyTexture(tex)
+
+
+def _shade_setup(gpu, W, H, result_format):
+    import pbrhip
+    from pbrhip import synth
+    L = gpu
+    gbd = synth.synth_gbuffer_spheres(W, H)
+    env = synth.synth_env(64, seed=0x5EED00AA)
+    env_tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, 64, 64, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+    maps = pbrhip.PBR_IBLMaps()
+    L.PBR_MakeIBLMaps(C.byref(maps), 32, 256, 64)
+    L.PBR_GenIrradianceMap(env_tex, maps.irradiance_map)
+    L.PBR_GenPrefilteredEnvMap(env_tex, maps.tex_specular_env_map, 16)
+    L.PBR_GenBRDFIntegrationMap(maps.brdf_lut)
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), W, H, result_format)
+    for name, arr in (("base_color", gbd["base"]), ("normal", gbd["normal"]), ("orm", gbd["orm"]), ("emissive", gbd["emissive"]),
+                      ("depth", gbd["depth"])):
+        pbrhip.upload_mip(getattr(gb, name), 0, arr)
+    lp = L.PBR_MakeLightingPass(C.byref(gb), C.byref(maps), W, H)
+    glob = pbrhip.fill_globals(gbd["cam_pos"], aspect=W / H)
+    return gbd, env_tex, maps, gb, lp, glob
+
+
+def _oracle_shade(gpu, gbd, maps, glob, flags):
+    import pbrhip, pbr_oracle as O
+    irr = pbrhip.read_mip(maps.irradiance_map, 0)
+    n = maps.tex_specular_env_map.contents.mip_level_count
+    size = maps.tex_specular_env_map.contents.width
+    pyr = np.concatenate([pbrhip.read_mip(maps.tex_specular_env_map, m).ravel() for m in range(n)])
+    lut = pbrhip.read_mip(maps.brdf_lut, 0).view(np.uint16)
+    g = O.OrcGlobals.from_buffer_copy(bytes(glob))
+    return O.shade(g, gbd["base"], gbd["normal"], gbd["orm"], gbd["emissive"], gbd["depth"], flags=flags,
+                   irradiance_cube=irr, prefiltered_pyr=pyr, prefiltered_size=size, lut_half=lut)
+
+
+@pytest.mark.parametrize("mode", ["ibl", "live", "live_shafts"])
+def test_shade_fp32_vs_oracle(gpu, mode):
+    """K5 on a 256x144 synthetic metal-rough-spheres G-buffer, fp32 target, vs Oracle-B fed the same GPU-built maps."""
+    import pbrhip, pbr_oracle as O
+    W, H = 256, 144
+    gbd, env_tex, maps, gb, lp, glob = _shade_setup(gpu, W, H, pbrhip.Format_RGBA32F)
+    flags = {"ibl": pbrhip.Shade_IBL, "live": 0, "live_shafts": pbrhip.Shade_LightShafts}[mode]
+    gpu.GPUX_SetShadeFlags(gpu.PBR_LightingPipeline(lp), flags)
+    g = gpu.GPU_MakeGraph()
+    gpu.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
+    gpu.GPU_GraphSubmit(g); gpu.GPU_GraphWait(g)
+    got = pbrhip.read_mip(gb.lighting_result, 0)
+    oflags = {"ibl": O.SHADE_IBL, "live": 0, "live_shafts": O.SHADE_SHAFTS}[mode]
+    want = _oracle_shade(gpu, gbd, maps, glob, oflags)
+    assert (gbd["depth"] < 1).mean() > 0.1 and (gbd["depth"] == 1).mean() > 0.1   # both geometry and sky are present
+    assert rmse_rel(got, want) < REL
+    assert rel_err(got[..., :3], want[..., :3], floor=1e-2) < REL, rel_err(got[..., :3], want[..., :3], floor=1e-2)
+    gpu.GPU_DestroyGraph(g); gpu.PBR_DestroyLightingPass(lp); gpu.PBR_DestroyGBuffer(C.byref(gb))
+    gpu.PBR_DestroyIBLMaps(C.byref(maps)); gpu.GPU_DestroyTexture(env_tex)
+
+
+def test_shade_fp16_target(gpu):
+    """RGBA16F target (render.cpp:693): bits equal to RTE(oracle fp32) or one ulp away."""
+    import pbrhip, pbr_oracle as O
+    W, H = 128, 72
+    gbd, env_tex, maps, gb, lp, glob = _shade_setup(gpu, W, H, pbrhip.Format_RGBA16F)
+    g = gpu.GPU_MakeGraph()
+    gpu.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
+    gpu.GPU_GraphSubmit(g); gpu.GPU_GraphWait(g)
+    got = pbrhip.read_mip(gb.lighting_result, 0).view(np.uint16).astype(np.int32)
+    want = _oracle_shade(gpu, gbd, maps, glob, O.SHADE_IBL).astype(np.float16).view(np.uint16).astype(np.int32)
+    assert np.abs(got - want).max() <= 1
+    gpu.GPU_DestroyGraph(g); gpu.PBR_DestroyLightingPass(lp); gpu.PBR_DestroyGBuffer(C.byref(gb))
+    gpu.PBR_DestroyIBLMaps(C.byref(maps)); gpu.GPU_DestroyTexture(env_tex)
+
+
+def test_lighting_tile_vs_oracle_a(gpu, golden_dir):
+    """K5 through the low-level kernel ABI on the Oracle-A lighting tile is covered on CPU for the oracle;
+    here: the sharded draw (GPUX_OpDrawRows) equals the full draw."""
+    import pbrhip
+    W, H = 128, 72
+    gbd, env_tex, maps, gb, lp, glob = _shade_setup(gpu, W, H, pbrhip.Format_RGBA32F)
+    g = gpu.GPU_MakeGraph()
+    gpu.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
+    gpu.GPU_GraphSubmit(g); gpu.GPU_GraphWait(g)
+    full = pbrhip.read_mip(gb.lighting_result, 0)
+    gpu.GPU_OpClearColorF(g, gb.lighting_result, 0, 0.0, 0.0, 0.0, 0.0)
+    for r0, r1 in ((0, 17), (17, 50), (50, 72)):
+        gpu.PBR_RecordLightingPass(lp, g, C.byref(glob), r0, r1)
+    gpu.GPU_GraphSubmit(g); gpu.GPU_GraphWait(g)
+    banded = pbrhip.read_mip(gb.lighting_result, 0)
+    assert np.array_equal(full.view(np.uint32), banded.view(np.uint32))
+    gpu.GPU_DestroyGraph(g); gpu.PBR_DestroyLightingPass(lp); gpu.PBR_DestroyGBuffer(C.byref(gb))
+    gpu.PBR_DestroyIBLMaps(C.byref(maps)); gpu.GPU_DestroyTexture(env_tex)
+
+
+def test_sharded_units_equal_full_dispatch(gpu, env64):
+    """Work-unit dispatch (multi-GPU sharding path) reproduces the single full dispatch bit for bit."""
+    import pbrhip
+    env, tex = env64
+    L = gpu
+    full = _run_prefilter(gpu, tex, 64, 1)
+    maps = pbrhip.PBR_IBLMaps()
+    L.PBR_MakeIBLMaps(C.byref(maps), 32, 64, 64)
+    pipes = L.PBR_MakeIBLPipelines()
+    arena = L.GPU_MakeDescriptorArena()
+    g = L.GPU_MakeGraph()
+    for rank in range(3):
+        units, n = pbrhip.partition(64, 1, 32, 64, 3, rank)
+        L.PBR_RecordUnits(pipes, g, arena, tex, C.byref(maps), units, n)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    for m in range(7):
+        a = pbrhip.read_mip(full, m); b = pbrhip.read_mip(maps.tex_specular_env_map, m)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"mip {m}"
+    irr_full = pbrhip.make_texture(pbrhip.Format_RGBA32F, 32, 32, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_StorageImage)
+    L.PBR_GenIrradianceMap(tex, irr_full)
+    assert np.array_equal(pbrhip.read_mip(irr_full, 0).view(np.uint32), pbrhip.read_mip(maps.irradiance_map, 0).view(np.uint32))
+    L.GPU_DestroyGraph(g); L.GPU_DestroyDescriptorArena(arena); L.PBR_DestroyIBLPipelines(pipes)
+    L.PBR_DestroyIBLMaps(C.byref(maps)); L.GPU_DestroyTexture(full); L.GPU_DestroyTexture(irr_full)

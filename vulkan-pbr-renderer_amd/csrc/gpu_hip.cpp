@@ -1,0 +1,1124 @@
+// gpu_hip.cpp -- HIP / gfx950 implementation of the GPU_* boundary declared in include/gpu_hip.h.
+//
+// Takes the place of src/gpu/gpu_vulkan.c for the IBL-precompute and shade hot path:
+//   * textures/buffers are linear HBM allocations (cube = [mip][face][y][x], tight);
+//   * sampled cubes carry a lazily rebuilt "bordered" twin (seamless-filter apron, k_cube.hip);
+//   * descriptor sets are plain slot arrays resolved by binding NAME at launch;
+//   * compute / graphics pipelines resolve to built-in kernels by shader identity;
+//   * a graph is a HIP stream plus a recorded op list, launched at GPU_GraphSubmit.
+// Error convention follows gpu_vulkan.c:6-8,387-392: print "GPU-ERROR: ..." and trap, unless a
+// handler was installed through GPUX_SetErrorHandler.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "gpux.h"
+#include "pbr_kernels.h"
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static GPUX_ErrorHandler g_err_handler = nullptr;
+static void* g_err_user = nullptr;
+
+static void gpu_fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (g_err_handler) { g_err_handler(buf, g_err_user); return; }
+    fprintf(stderr, "GPU-ERROR: %s\n", buf);
+    fflush(stderr);
+    abort();
+}
+#define GPU_REQUIRE(cond, ret, ...) do { if (!(cond)) { gpu_fail(__VA_ARGS__); return ret; } } while (0)
+#define GPU_REQUIRE_V(cond, ...) do { if (!(cond)) { gpu_fail(__VA_ARGS__); return; } } while (0)
+#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gpu_fail("%s: HIP call failed: %s (%s)", __func__, #call, hipGetErrorString(e_)); } } while (0)
+
+// ------------------------------------------------------------------------------------------
+// object model
+// ------------------------------------------------------------------------------------------
+enum BindKind { Bind_Texture, Bind_Sampler, Bind_Buffer, Bind_StorageImage };
+enum KernelId { Kernel_None = 0, Kernel_BrdfLut, Kernel_Irradiance, Kernel_Prefilter, Kernel_Lighting };
+
+struct GPU_Sampler { GPU_SamplerDesc desc; bool shared; };
+
+struct LayoutBinding { std::string name; BindKind kind; GPU_Format format; };
+struct GPU_PipelineLayout { std::vector<LayoutBinding> bindings; bool finalized = false; };
+
+struct TextureImpl {
+    GPU_Texture base;                 // public part first (gpu_vulkan.c:182-205 does the same)
+    void* dev = nullptr;              // [mip][layer][z][y][x]
+    size_t bytes = 0;
+    std::vector<size_t> mip_offset;   // bytes
+    uint32_t texel_bytes = 0;
+    void* bordered = nullptr;         // bordered pyramid twin (RGBA32F cubes only), built on demand
+    size_t bordered_bytes = 0;
+    bool bordered_valid = false;
+};
+struct BufferImpl {
+    GPU_Buffer base;
+    void* dev = nullptr;              // device-visible pointer (== base.data for CPU buffers)
+    bool pinned_host = false;
+};
+
+struct Slot { BindKind kind; bool set = false; TextureImpl* tex = nullptr; uint32_t mip = 0; bool whole = true;
+              GPU_Sampler* sampler = nullptr; BufferImpl* buf = nullptr; };
+struct GPU_DescriptorSet { GPU_PipelineLayout* layout; std::vector<Slot> slots; bool finalized = false; GPU_DescriptorArena* arena = nullptr; };
+struct GPU_DescriptorArena { std::vector<GPU_DescriptorSet*> sets; };
+
+struct GPU_ComputePipeline { GPU_PipelineLayout* layout; KernelId kernel; };
+struct GPU_RenderPass { GPU_RenderPassDesc desc; std::vector<GPU_TextureView> targets; };
+struct GPU_GraphicsPipeline { GPU_PipelineLayout* layout; GPU_RenderPass* pass; KernelId kernel; int shade_flags; };
+
+enum OpKind { Op_Dispatch, Op_Shade, Op_MipGen, Op_CopyB2T, Op_CopyT2B, Op_CopyB2B, Op_Blit, Op_Clear };
+struct Op {
+    OpKind kind;
+    std::string name;
+    // dispatch
+    GPU_ComputePipeline* cpipe = nullptr;
+    GPU_DescriptorSet* set = nullptr;
+    uint8_t push[128]; uint32_t push_size = 0;
+    uint32_t face0 = 0, face1 = 6, row0 = 0, row1 = 0;
+    bool rows_explicit = false;
+    uint32_t gx = 0, gy = 0, gz = 0;
+    // shade
+    GPU_GraphicsPipeline* gpipe = nullptr;
+    GPU_RenderPass* pass = nullptr;
+    // transfers
+    TextureImpl* tex = nullptr; TextureImpl* tex2 = nullptr;
+    BufferImpl* buf = nullptr; BufferImpl* buf2 = nullptr;
+    uint32_t mip = 0, mip2 = 0, layer0 = 0, layer_count = 0, layer2 = 0;
+    uint64_t off_a = 0, off_b = 0, size = 0;
+    float clear[4]; uint32_t cleari[4]; int clear_mode = 0;
+};
+struct DrawParams { GPU_GraphicsPipeline* pipeline; GPU_DescriptorSet* set; };
+struct GPU_Graph {
+    hipStream_t stream = nullptr;
+    std::vector<Op> ops;
+    bool submitted = false;
+    GPU_ComputePipeline* bound_cpipe = nullptr;
+    GPU_DescriptorSet* bound_cset = nullptr;
+    uint8_t push[128]; uint32_t push_size = 0;
+    GPU_RenderPass* preparing = nullptr; GPU_RenderPass* in_pass = nullptr;
+    std::vector<DrawParams> draw_params;
+    int bound_draw = -1;
+    // timing of the last waited submission
+    std::vector<hipEvent_t> ev;
+    std::vector<std::string> timed_names;
+    std::vector<float> timed_ms;
+};
+
+struct DeviceTable { void* dev = nullptr; int count = 0; float alpha = 0.0f; };
+struct TableKey {
+    int kind, n, aux; uint32_t rbits;
+    bool operator<(const TableKey& o) const {
+        if (kind != o.kind) return kind < o.kind;
+        if (n != o.n) return n < o.n;
+        if (aux != o.aux) return aux < o.aux;
+        return rbits < o.rbits;
+    }
+};
+
+static struct {
+    bool init = false;
+    int device = -1;
+    GPU_Sampler samplers[6];
+    std::map<TableKey, DeviceTable> tables;
+    bool timing = false;
+} G;
+
+static const char kTokenLut[] = "HIPK1:gen_brdf_integration_map";
+static const char kTokenIrr[] = "HIPK3:gen_irradiance_map";
+static const char kTokenPre[] = "HIPK4:gen_prefiltered_env_map";
+static const char kTokenLit[] = "HIPK5:lighting_pass";
+
+// ------------------------------------------------------------------------------------------
+// formats  [gpu.h:99-144]
+// ------------------------------------------------------------------------------------------
+GPU_API GPU_FormatInfo GPUX_GetFormatInfo(GPU_Format f) {
+    struct Row { GPU_Format f; uint32_t ext, size; bool s, v, c, d, st, i; const char* glsl; };
+    static const Row rows[] = {
+        {GPU_Format_R8UN, 1, 1, 1, 1, 1, 0, 0, 0, "r8"}, {GPU_Format_RG8UN, 1, 2, 1, 1, 1, 0, 0, 0, "rg8"},
+        {GPU_Format_RGBA8UN, 1, 4, 1, 1, 1, 0, 0, 0, "rgba8"}, {GPU_Format_BGRA8UN, 1, 4, 1, 1, 1, 0, 0, 0, nullptr},
+        {GPU_Format_R16F, 1, 2, 1, 1, 1, 0, 0, 0, "r16f"}, {GPU_Format_RG16F, 1, 4, 1, 1, 1, 0, 0, 0, "rg16f"},
+        {GPU_Format_RGB16F, 1, 6, 0, 1, 0, 0, 0, 0, nullptr}, {GPU_Format_RGBA16F, 1, 8, 1, 1, 1, 0, 0, 0, "rgba16f"},
+        {GPU_Format_R32F, 1, 4, 1, 1, 1, 0, 0, 0, "r32f"}, {GPU_Format_RG32F, 1, 8, 1, 1, 1, 0, 0, 0, "rg32f"},
+        {GPU_Format_RGB32F, 1, 12, 0, 1, 0, 0, 0, 0, nullptr}, {GPU_Format_RGBA32F, 1, 16, 1, 1, 1, 0, 0, 0, "rgba32f"},
+        {GPU_Format_R8I, 1, 1, 1, 1, 1, 0, 0, 1, "r8ui"}, {GPU_Format_R16I, 1, 2, 1, 1, 1, 0, 0, 1, "r16ui"},
+        {GPU_Format_RG16I, 1, 4, 1, 1, 1, 0, 0, 1, "rg16ui"}, {GPU_Format_RGBA16I, 1, 8, 1, 1, 1, 0, 0, 1, "rgba16ui"},
+        {GPU_Format_R32I, 1, 4, 1, 1, 1, 0, 0, 1, "r32ui"}, {GPU_Format_RG32I, 1, 8, 1, 1, 1, 0, 0, 1, "rg32ui"},
+        {GPU_Format_RGB32I, 1, 12, 1, 1, 0, 0, 0, 1, nullptr}, {GPU_Format_RGBA32I, 1, 16, 1, 1, 1, 0, 0, 1, "rgba32ui"},
+        {GPU_Format_R64I, 1, 8, 0, 0, 0, 0, 0, 1, "r64ui"}, {GPU_Format_D16UN, 1, 2, 1, 0, 0, 1, 0, 0, nullptr},
+        {GPU_Format_D32F_Or_X8D24UN, 1, 4, 1, 0, 0, 1, 0, 0, nullptr}, {GPU_Format_D32FS8I_Or_D24UNS8I, 1, 5, 0, 0, 0, 1, 0, 0, nullptr},
+        {GPU_Format_D24UNS8I_Or_D32FS8I, 1, 4, 0, 0, 0, 1, 0, 0, nullptr},
+        {GPU_Format_BC1_RGB_UN, 4, 8, 1, 0, 0, 0, 0, 0, nullptr}, {GPU_Format_BC1_RGBA_UN, 4, 8, 1, 0, 0, 0, 0, 0, nullptr},
+        {GPU_Format_BC3_RGBA_UN, 4, 16, 1, 0, 0, 0, 0, 0, nullptr}, {GPU_Format_BC5_UN, 4, 16, 1, 0, 0, 0, 0, 0, nullptr},
+    };
+    for (const Row& r : rows)
+        if (r.f == f) { GPU_FormatInfo o = {r.ext, r.size, r.s, r.v, r.c, r.d, r.st, r.i, r.glsl}; return o; }
+    GPU_FormatInfo z = {0, 0, false, false, false, false, false, false, nullptr};
+    return z;
+}
+
+// ------------------------------------------------------------------------------------------
+// lifetime
+// ------------------------------------------------------------------------------------------
+GPU_API void GPUX_SetDevice(int idx) { G.device = idx; }
+GPU_API int GPUX_GetDevice(void) { return G.device; }
+GPU_API void GPUX_SetErrorHandler(GPUX_ErrorHandler h, void* user) { g_err_handler = h; g_err_user = user; }
+GPU_API const char* GPUX_BackendName(void) { return "hip-gfx950"; }
+
+static void make_shared_sampler(GPU_Sampler* s, GPU_Filter f, GPU_AddressMode m) {
+    memset(&s->desc, 0, sizeof s->desc);
+    s->desc.min_filter = s->desc.mag_filter = s->desc.mipmap_mode = f;     // gpu_vulkan.c:935-943
+    s->desc.address_modes[0] = s->desc.address_modes[1] = s->desc.address_modes[2] = m;
+    s->desc.max_lod = 1000.0f;
+    s->shared = true;
+}
+
+GPU_API void GPU_Init(GPU_WindowHandle window) {
+    (void)window;   // headless
+    GPU_REQUIRE_V(!G.init, "GPU_Init: already initialised");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    GPU_REQUIRE_V(e == hipSuccess && count > 0, "GPU_Init: no HIP device (%s)", hipGetErrorString(e));
+    if (G.device < 0) {
+        const char* lr = getenv("LOCAL_RANK");
+        G.device = lr ? atoi(lr) % count : 0;
+    }
+    GPU_REQUIRE_V(G.device < count, "GPU_Init: device %d out of range (%d devices)", G.device, count);
+    HIP_OK(hipSetDevice(G.device));
+    make_shared_sampler(&G.samplers[0], GPU_Filter_Linear, GPU_AddressMode_Wrap);
+    make_shared_sampler(&G.samplers[1], GPU_Filter_Linear, GPU_AddressMode_Clamp);
+    make_shared_sampler(&G.samplers[2], GPU_Filter_Linear, GPU_AddressMode_Mirror);
+    make_shared_sampler(&G.samplers[3], GPU_Filter_Nearest, GPU_AddressMode_Clamp);
+    make_shared_sampler(&G.samplers[4], GPU_Filter_Nearest, GPU_AddressMode_Wrap);
+    make_shared_sampler(&G.samplers[5], GPU_Filter_Nearest, GPU_AddressMode_Mirror);
+    G.init = true;
+}
+
+GPU_API void GPU_Deinit(void) {
+    if (!G.init) return;
+    hipDeviceSynchronize();
+    for (auto& kv : G.tables) hipFree(kv.second.dev);
+    G.tables.clear();
+    G.init = false;
+}
+
+GPU_API void GPU_WaitUntilIdle(void) { if (G.init) HIP_OK(hipDeviceSynchronize()); }
+
+// ------------------------------------------------------------------------------------------
+// samplers
+// ------------------------------------------------------------------------------------------
+GPU_API GPU_Sampler* GPU_SamplerLinearWrap(void) { return &G.samplers[0]; }
+GPU_API GPU_Sampler* GPU_SamplerLinearClamp(void) { return &G.samplers[1]; }
+GPU_API GPU_Sampler* GPU_SamplerLinearMirror(void) { return &G.samplers[2]; }
+GPU_API GPU_Sampler* GPU_SamplerNearestClamp(void) { return &G.samplers[3]; }
+GPU_API GPU_Sampler* GPU_SamplerNearestWrap(void) { return &G.samplers[4]; }
+GPU_API GPU_Sampler* GPU_SamplerNearestMirror(void) { return &G.samplers[5]; }
+GPU_API GPU_Sampler* GPU_MakeSampler(const GPU_SamplerDesc* desc) {
+    GPU_REQUIRE(desc, nullptr, "GPU_MakeSampler: desc is NULL");
+    GPU_Sampler* s = new GPU_Sampler();
+    s->desc = *desc; s->shared = false;
+    return s;
+}
+GPU_API void GPU_DestroySampler(GPU_Sampler* s) {
+    if (!s) return;
+    GPU_REQUIRE_V(!s->shared, "GPU_DestroySampler: shared sampler shortcuts must not be destroyed");
+    delete s;
+}
+
+// ------------------------------------------------------------------------------------------
+// pipeline layouts
+// ------------------------------------------------------------------------------------------
+GPU_API GPU_PipelineLayout* GPU_InitPipelineLayout(void) { return new GPU_PipelineLayout(); }
+static GPU_Binding add_binding(GPU_PipelineLayout* l, const char* name, BindKind k, GPU_Format f, const char* fn) {
+    GPU_REQUIRE(l && name, 0, "%s: NULL argument", fn);
+    GPU_REQUIRE(!l->finalized, 0, "%s: layout already finalised", fn);
+    l->bindings.push_back({name, k, f});
+    return (GPU_Binding)(l->bindings.size() - 1);
+}
+GPU_API GPU_Binding GPU_TextureBinding(GPU_PipelineLayout* l, const char* name) { return add_binding(l, name, Bind_Texture, GPU_Format_Invalid, __func__); }
+GPU_API GPU_Binding GPU_SamplerBinding(GPU_PipelineLayout* l, const char* name) { return add_binding(l, name, Bind_Sampler, GPU_Format_Invalid, __func__); }
+GPU_API GPU_Binding GPU_BufferBinding(GPU_PipelineLayout* l, const char* name) { return add_binding(l, name, Bind_Buffer, GPU_Format_Invalid, __func__); }
+GPU_API GPU_Binding GPU_StorageImageBinding(GPU_PipelineLayout* l, const char* name, GPU_Format f) { return add_binding(l, name, Bind_StorageImage, f, __func__); }
+GPU_API void GPU_FinalizePipelineLayout(GPU_PipelineLayout* l) {
+    GPU_REQUIRE_V(l, "GPU_FinalizePipelineLayout: NULL layout");
+    l->finalized = true;
+}
+GPU_API void GPU_DestroyPipelineLayout(GPU_PipelineLayout* l) { delete l; }
+
+static int find_binding(const GPU_PipelineLayout* l, const char* name) {
+    for (size_t i = 0; i < l->bindings.size(); ++i) if (l->bindings[i].name == name) return (int)i;
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------------
+// descriptor sets
+// ------------------------------------------------------------------------------------------
+GPU_API GPU_DescriptorArena* GPU_MakeDescriptorArena(void) { return new GPU_DescriptorArena(); }
+GPU_API void GPU_ResetDescriptorArena(GPU_DescriptorArena* a) {
+    GPU_REQUIRE_V(a, "GPU_ResetDescriptorArena: NULL arena");
+    for (GPU_DescriptorSet* s : a->sets) delete s;
+    a->sets.clear();
+}
+GPU_API void GPU_DestroyDescriptorArena(GPU_DescriptorArena* a) {
+    if (!a) return;
+    for (GPU_DescriptorSet* s : a->sets) delete s;
+    delete a;
+}
+GPU_API GPU_DescriptorSet* GPU_InitDescriptorSet(GPU_DescriptorArena* arena, GPU_PipelineLayout* layout) {
+    GPU_REQUIRE(layout && layout->finalized, nullptr, "GPU_InitDescriptorSet: layout is NULL or not finalised");
+    GPU_DescriptorSet* s = new GPU_DescriptorSet();
+    s->layout = layout;
+    s->slots.resize(layout->bindings.size());
+    for (size_t i = 0; i < s->slots.size(); ++i) s->slots[i].kind = layout->bindings[i].kind;
+    s->arena = arena;
+    if (arena) arena->sets.push_back(s);
+    return s;
+}
+static Slot* slot_for(GPU_DescriptorSet* set, GPU_Binding b, BindKind kind, const char* fn) {
+    GPU_REQUIRE(set, nullptr, "%s: NULL descriptor set", fn);
+    GPU_REQUIRE(!set->finalized, nullptr, "%s: descriptor set already finalised", fn);
+    GPU_REQUIRE(b < set->slots.size(), nullptr, "%s: binding %u out of range", fn, b);
+    GPU_REQUIRE(set->slots[b].kind == kind, nullptr, "%s: binding %u (\"%s\") has a different kind", fn, b, set->layout->bindings[b].name.c_str());
+    return &set->slots[b];
+}
+GPU_API void GPU_SetTextureBinding(GPU_DescriptorSet* set, GPU_Binding b, GPU_Texture* v) {
+    Slot* s = slot_for(set, b, Bind_Texture, __func__); if (!s) return;
+    GPU_REQUIRE_V(v, "GPU_SetTextureBinding: NULL texture");
+    s->tex = (TextureImpl*)v; s->whole = true; s->mip = 0; s->set = true;
+}
+GPU_API void GPU_SetTextureMipBinding(GPU_DescriptorSet* set, GPU_Binding b, GPU_Texture* v, uint32_t mip) {
+    Slot* s = slot_for(set, b, Bind_Texture, __func__); if (!s) return;
+    GPU_REQUIRE_V(v && mip < v->mip_level_count, "GPU_SetTextureMipBinding: bad texture / mip");
+    GPU_REQUIRE_V(v->flags & GPU_TextureFlag_PerMipBinding, "GPU_SetTextureMipBinding: texture lacks GPU_TextureFlag_PerMipBinding");
+    s->tex = (TextureImpl*)v; s->whole = false; s->mip = mip; s->set = true;
+}
+GPU_API void GPU_SetSamplerBinding(GPU_DescriptorSet* set, GPU_Binding b, GPU_Sampler* v) {
+    Slot* s = slot_for(set, b, Bind_Sampler, __func__); if (!s) return;
+    GPU_REQUIRE_V(v, "GPU_SetSamplerBinding: NULL sampler");
+    s->sampler = v; s->set = true;
+}
+GPU_API void GPU_SetBufferBinding(GPU_DescriptorSet* set, GPU_Binding b, GPU_Buffer* v) {
+    Slot* s = slot_for(set, b, Bind_Buffer, __func__); if (!s) return;
+    GPU_REQUIRE_V(v, "GPU_SetBufferBinding: NULL buffer");
+    s->buf = (BufferImpl*)v; s->set = true;
+}
+GPU_API void GPU_SetStorageImageBinding(GPU_DescriptorSet* set, GPU_Binding b, GPU_Texture* v, uint32_t mip) {
+    Slot* s = slot_for(set, b, Bind_StorageImage, __func__); if (!s) return;
+    GPU_REQUIRE_V(v && mip < v->mip_level_count, "GPU_SetStorageImageBinding: bad texture / mip level %u", mip);
+    GPU_REQUIRE_V(v->flags & GPU_TextureFlag_StorageImage, "GPU_SetStorageImageBinding: texture lacks GPU_TextureFlag_StorageImage");
+    s->tex = (TextureImpl*)v; s->whole = false; s->mip = mip; s->set = true;
+}
+GPU_API void GPU_FinalizeDescriptorSet(GPU_DescriptorSet* set) {
+    GPU_REQUIRE_V(set, "GPU_FinalizeDescriptorSet: NULL set");
+    for (size_t i = 0; i < set->slots.size(); ++i)
+        GPU_REQUIRE_V(set->slots[i].set, "GPU_FinalizeDescriptorSet: binding %zu (\"%s\") was never set", i, set->layout->bindings[i].name.c_str());
+    set->finalized = true;
+}
+GPU_API void GPU_DestroyDescriptorSet(GPU_DescriptorSet* set) {
+    if (!set) return;
+    GPU_REQUIRE_V(!set->arena, "GPU_DestroyDescriptorSet: set belongs to an arena");
+    delete set;
+}
+
+// ------------------------------------------------------------------------------------------
+// resources
+// ------------------------------------------------------------------------------------------
+static inline uint32_t mip_dim(uint32_t d, uint32_t m) { uint32_t v = d >> m; return v < 1 ? 1 : v; }
+
+GPU_API uint64_t GPUX_TextureMipBytes(const GPU_Texture* t, uint32_t mip) {
+    if (!t || mip >= t->mip_level_count) return 0;
+    GPU_FormatInfo fi = GPUX_GetFormatInfo(t->format);
+    uint64_t w = mip_dim(t->width, mip), h = mip_dim(t->height, mip), d = mip_dim(t->depth, mip);
+    uint64_t bw = (w + fi.block_extent - 1) / fi.block_extent, bh = (h + fi.block_extent - 1) / fi.block_extent;
+    return bw * bh * d * fi.block_size * t->layer_count;
+}
+
+static bool is_f4_cube(const TextureImpl* t) {
+    return t->base.format == GPU_Format_RGBA32F && (t->base.flags & GPU_TextureFlag_Cubemap) && t->base.width == t->base.height && t->base.depth == 1;
+}
+
+GPU_API GPU_Texture* GPU_MakeTexture(GPU_Format format, uint32_t width, uint32_t height, uint32_t depth, GPU_TextureFlags flags, const void* data) {
+    GPU_REQUIRE(G.init, nullptr, "GPU_MakeTexture: GPU_Init has not been called");
+    GPU_REQUIRE(width > 0 && height > 0 && depth > 0, nullptr, "GPU_MakeTexture: zero extent");   // gpu_vulkan.c:1339
+    GPU_FormatInfo fi = GPUX_GetFormatInfo(format);
+    GPU_REQUIRE(fi.block_size > 0, nullptr, "GPU_MakeTexture: invalid format %d", (int)format);
+    TextureImpl* t = new TextureImpl();
+    t->base.width = width; t->base.height = height; t->base.depth = depth;
+    t->base.layer_count = (flags & GPU_TextureFlag_Cubemap) ? 6 : 1;
+    uint32_t mips = 1;
+    if (flags & GPU_TextureFlag_HasMipmaps) {                                  // gpu_vulkan.c:1344-1351
+        uint32_t s = width < height ? width : height;
+        while (s > 1) { s /= 2; mips++; }
+    }
+    t->base.mip_level_count = mips;
+    t->base.format = format; t->base.flags = flags;
+    t->texel_bytes = fi.block_size;
+    size_t off = 0;
+    for (uint32_t m = 0; m < mips; ++m) { t->mip_offset.push_back(off); off += (size_t)GPUX_TextureMipBytes(&t->base, m); }
+    t->bytes = off;
+    hipError_t e = hipMalloc(&t->dev, t->bytes);
+    if (e != hipSuccess) { gpu_fail("GPU_MakeTexture: hipMalloc(%zu) failed: %s", t->bytes, hipGetErrorString(e)); delete t; return nullptr; }
+    HIP_OK(hipMemset(t->dev, 0, t->bytes));
+    if (data) {
+        HIP_OK(hipMemcpy(t->dev, data, (size_t)GPUX_TextureMipBytes(&t->base, 0), hipMemcpyHostToDevice));
+        if (mips > 1) {                                                        // gpu_vulkan.c:1444-1446
+            if (!is_f4_cube(t) || (width & (width - 1))) {
+                gpu_fail("GPU_MakeTexture: mip generation is implemented for power-of-two RGBA32F cubemaps only");
+            } else {
+                int rc = pbrk_mip_chain(t->dev, (int)width, (int)mips, nullptr);
+                if (rc != PBRK_OK) gpu_fail("GPU_MakeTexture: mip chain kernel failed (%d)", rc);
+                HIP_OK(hipStreamSynchronize(nullptr));                          // :1448-1449 blocking
+            }
+        }
+    }
+    return &t->base;
+}
+
+GPU_API void GPU_DestroyTexture(GPU_Texture* tex) {
+    if (!tex) return;
+    TextureImpl* t = (TextureImpl*)tex;
+    hipFree(t->dev);
+    if (t->bordered) hipFree(t->bordered);
+    delete t;
+}
+
+GPU_API GPU_Buffer* GPU_MakeBuffer(uint32_t size, GPU_BufferFlags flags, const void* data) {
+    GPU_REQUIRE(G.init, nullptr, "GPU_MakeBuffer: GPU_Init has not been called");
+    GPU_REQUIRE(size > 0, nullptr, "GPU_MakeBuffer: zero size");
+    BufferImpl* b = new BufferImpl();
+    b->base.flags = flags; b->base.size = size; b->base.data = nullptr;
+    hipError_t e;
+    if (flags & GPU_BufferFlag_CPU) {                                          // persistently mapped (gpu_vulkan.c:1248-1250)
+        e = hipHostMalloc(&b->dev, size, hipHostMallocDefault);
+        b->pinned_host = true;
+        b->base.data = b->dev;
+    } else {
+        e = hipMalloc(&b->dev, size);
+    }
+    if (e != hipSuccess) { gpu_fail("GPU_MakeBuffer: allocation of %u bytes failed: %s", size, hipGetErrorString(e)); delete b; return nullptr; }
+    if (data) {
+        if (b->pinned_host) memcpy(b->dev, data, size);
+        else HIP_OK(hipMemcpy(b->dev, data, size, hipMemcpyHostToDevice));
+    }
+    return &b->base;
+}
+
+GPU_API void GPU_DestroyBuffer(GPU_Buffer* buf) {
+    if (!buf) return;
+    BufferImpl* b = (BufferImpl*)buf;
+    if (b->pinned_host) hipHostFree(b->dev); else hipFree(b->dev);
+    delete b;
+}
+
+GPU_API void* GPUX_TextureDevicePtr(GPU_Texture* tex, uint32_t mip) {
+    GPU_REQUIRE(tex && mip < tex->mip_level_count, nullptr, "GPUX_TextureDevicePtr: bad texture / mip");
+    TextureImpl* t = (TextureImpl*)tex;
+    return (char*)t->dev + t->mip_offset[mip];
+}
+GPU_API void* GPUX_BufferDevicePtr(GPU_Buffer* buf) { return buf ? ((BufferImpl*)buf)->dev : nullptr; }
+
+// ------------------------------------------------------------------------------------------
+// pipelines: shader identity -> built-in kernel
+// ------------------------------------------------------------------------------------------
+static std::string basename_of(GPU_String path) {
+    std::string s(path.data ? path.data : "", path.data ? path.length : 0);
+    size_t p = s.find_last_of("/\\");
+    return p == std::string::npos ? s : s.substr(p + 1);
+}
+static bool glsl_contains(GPU_String glsl, const char* needle) {
+    if (!glsl.data || glsl.length == 0) return true;        // no text given: trust the file name
+    std::string s(glsl.data, glsl.length);
+    return s.find(needle) != std::string::npos;
+}
+static KernelId identify_shader(const GPU_ShaderDesc* d) {
+    if (d->spirv.data && d->spirv.length) {
+        std::string t(d->spirv.data, d->spirv.length);
+        if (t == kTokenLut) return Kernel_BrdfLut;
+        if (t == kTokenIrr) return Kernel_Irradiance;
+        if (t == kTokenPre) return Kernel_Prefilter;
+        if (t == kTokenLit) return Kernel_Lighting;
+        return Kernel_None;
+    }
+    std::string b = basename_of(d->glsl_debug_filepath);
+    // file name first; the GLSL text (when present) must carry the entry's signature symbols
+    if (b == "gen_brdf_integration_map.glsl" && glsl_contains(d->glsl, "GeometryMikkelsen") && glsl_contains(d->glsl, "image2D OUTPUT")) return Kernel_BrdfLut;
+    if (b == "gen_irradiance_map.glsl" && glsl_contains(d->glsl, "CubemapSampleDirFromFaceUV") && glsl_contains(d->glsl, "TEX_ENV_CUBE")) return Kernel_Irradiance;
+    if (b == "gen_prefiltered_env_map.glsl" && glsl_contains(d->glsl, "DistributionBeckmann") && glsl_contains(d->glsl, "mip_level")) return Kernel_Prefilter;
+    if (b == "lighting_pass.glsl" && glsl_contains(d->glsl, "BRDF_INTEGRATION_MAP") && glsl_contains(d->glsl, "GBUFFER_DEPTH")) return Kernel_Lighting;
+    return Kernel_None;
+}
+static GPU_String token_for(KernelId k) {
+    switch (k) {
+    case Kernel_BrdfLut: return GPU_String{kTokenLut, sizeof kTokenLut - 1};
+    case Kernel_Irradiance: return GPU_String{kTokenIrr, sizeof kTokenIrr - 1};
+    case Kernel_Prefilter: return GPU_String{kTokenPre, sizeof kTokenPre - 1};
+    case Kernel_Lighting: return GPU_String{kTokenLit, sizeof kTokenLit - 1};
+    default: return GPU_String{nullptr, 0};
+    }
+}
+
+static GPU_GLSLError g_last_error;
+static char g_last_error_text[512];
+
+GPU_API GPU_String GPU_SPIRVFromGLSL(DS_Arena* arena, GPU_ShaderStage stage, GPU_PipelineLayout* layout, const GPU_ShaderDesc* desc, GPU_GLSLErrorArray* out_errors) {
+    (void)arena; (void)layout;
+    GPU_String empty = {nullptr, 0};
+    GPU_REQUIRE(desc, empty, "GPU_SPIRVFromGLSL: NULL shader desc");
+    GPU_ShaderDesc probe = *desc;
+    probe.spirv = empty;
+    KernelId k = identify_shader(&probe);
+    bool stage_ok = (k == Kernel_Lighting) ? (stage == GPU_ShaderStage_Vertex || stage == GPU_ShaderStage_Fragment)
+                                           : (stage == GPU_ShaderStage_Compute);
+    if (k != Kernel_None && stage_ok) {
+        if (out_errors) { out_errors->data = nullptr; out_errors->length = 0; }
+        return token_for(k);
+    }
+    snprintf(g_last_error_text, sizeof g_last_error_text,
+             "the HIP backend has no built-in kernel for shader \"%s\" (stage %d); supported: gen_brdf_integration_map.glsl, "
+             "gen_irradiance_map.glsl, gen_prefiltered_env_map.glsl (compute), lighting_pass.glsl (full-screen)",
+             basename_of(desc->glsl_debug_filepath).c_str(), (int)stage);
+    if (!out_errors) { gpu_fail("GPU_SPIRVFromGLSL: %s", g_last_error_text); return empty; }
+    g_last_error.shader_stage = stage; g_last_error.line = 0;
+    g_last_error.error_message = GPU_String{g_last_error_text, strlen(g_last_error_text)};
+    out_errors->data = &g_last_error; out_errors->length = 1;
+    return empty;
+}
+
+GPU_API GPU_String GPU_JoinGLSLErrorString(DS_Arena* arena, GPU_GLSLErrorArray errors) {
+    (void)arena;
+    static std::string joined;
+    joined.clear();
+    for (uint32_t i = 0; i < errors.length; ++i) {
+        char head[64];
+        snprintf(head, sizeof head, "line %u: ", errors.data[i].line);
+        joined += head;
+        joined.append(errors.data[i].error_message.data, errors.data[i].error_message.length);
+        joined += "\n";
+    }
+    return GPU_String{joined.c_str(), joined.size()};
+}
+
+GPU_API GPU_ComputePipeline* GPU_MakeComputePipeline(GPU_PipelineLayout* layout, const GPU_ShaderDesc* cs) {
+    GPU_REQUIRE(layout && layout->finalized && cs, nullptr, "GPU_MakeComputePipeline: NULL / unfinalised argument");
+    KernelId k = identify_shader(cs);
+    GPU_REQUIRE(k == Kernel_BrdfLut || k == Kernel_Irradiance || k == Kernel_Prefilter, nullptr,
+                "GPU_MakeComputePipeline: shader \"%s\" has no built-in HIP kernel", basename_of(cs->glsl_debug_filepath).c_str());
+    GPU_REQUIRE(find_binding(layout, "OUTPUT") >= 0, nullptr, "GPU_MakeComputePipeline: layout has no \"OUTPUT\" storage image");
+    if (k != Kernel_BrdfLut)
+        GPU_REQUIRE(find_binding(layout, "TEX_ENV_CUBE") >= 0, nullptr, "GPU_MakeComputePipeline: layout has no \"TEX_ENV_CUBE\" texture");
+    GPU_ComputePipeline* p = new GPU_ComputePipeline();
+    p->layout = layout; p->kernel = k;
+    return p;
+}
+GPU_API void GPU_DestroyComputePipeline(GPU_ComputePipeline* p) { delete p; }
+
+GPU_API GPU_RenderPass* GPU_MakeRenderPass(const GPU_RenderPassDesc* desc) {
+    GPU_REQUIRE(desc, nullptr, "GPU_MakeRenderPass: NULL desc");
+    GPU_REQUIRE(desc->color_targets != GPU_SWAPCHAIN_COLOR_TARGET, nullptr, "GPU_MakeRenderPass: swapchain targets are unsupported (headless backend)");
+    GPU_REQUIRE(desc->msaa_color_resolve_targets == nullptr, nullptr, "GPU_MakeRenderPass: MSAA is unsupported (raster)");
+    GPU_RenderPass* rp = new GPU_RenderPass();
+    rp->desc = *desc;
+    for (uint32_t i = 0; i < desc->color_targets_count; ++i) rp->targets.push_back(desc->color_targets[i]);
+    rp->desc.color_targets = rp->targets.data();
+    return rp;
+}
+GPU_API void GPU_DestroyRenderPass(GPU_RenderPass* rp) { delete rp; }
+
+GPU_API GPU_GraphicsPipeline* GPU_MakeGraphicsPipeline(const GPU_GraphicsPipelineDesc* desc) {
+    GPU_REQUIRE(desc && desc->layout && desc->render_pass, nullptr, "GPU_MakeGraphicsPipeline: NULL argument");
+    KernelId k = identify_shader(&desc->fs);
+    GPU_REQUIRE(k == Kernel_Lighting, nullptr,
+                "GPU_MakeGraphicsPipeline: unsupported (raster): only the full-screen lighting_pass.glsl pipeline has a HIP kernel (got \"%s\")",
+                basename_of(desc->fs.glsl_debug_filepath).c_str());
+    GPU_REQUIRE(desc->vertex_input_formats_count == 0, nullptr, "GPU_MakeGraphicsPipeline: unsupported (raster): vertex inputs");
+    GPU_REQUIRE(desc->render_pass->desc.color_targets_count == 1, nullptr, "GPU_MakeGraphicsPipeline: the lighting pass has exactly one colour target");
+    GPU_GraphicsPipeline* p = new GPU_GraphicsPipeline();
+    p->layout = desc->layout; p->pass = desc->render_pass; p->kernel = k; p->shade_flags = GPUX_Shade_IBL;
+    return p;
+}
+GPU_API void GPU_DestroyGraphicsPipeline(GPU_GraphicsPipeline* p) { delete p; }
+GPU_API void GPUX_SetShadeFlags(GPU_GraphicsPipeline* p, int flags) {
+    GPU_REQUIRE_V(p, "GPUX_SetShadeFlags: NULL pipeline");
+    p->shade_flags = flags;
+}
+
+// ------------------------------------------------------------------------------------------
+// host tables -> device (cached)
+// ------------------------------------------------------------------------------------------
+static uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+static DeviceTable* get_table(int kind, int n, float roughness, int aux) {
+    TableKey key = {kind, n, aux, fbits(roughness)};
+    auto it = G.tables.find(key);
+    if (it != G.tables.end()) return &it->second;
+    DeviceTable t;
+    std::vector<float> host;
+    if (kind == 0) {            // prefilter (lx,ly,lz,w)
+        host.resize((size_t)n * 4);
+        t.count = pbrk_host_prefilter_table(n, roughness, host.data(), &t.alpha);
+    } else if (kind == 1) {     // irradiance
+        host.resize((size_t)n * 4);
+        t.count = pbrk_host_irradiance_table(n, host.data());
+    } else if (kind == 2) {     // LUT sample angles
+        host.resize((size_t)n * 4);
+        pbrk_host_sample_angles(n, host.data());
+        t.count = n;
+    } else {                    // LUT per-column view angle: V = Rotate(N, X, acos(NdotV)), gen_brdf_integration_map.glsl:154-160
+        host.resize((size_t)n * 2);
+        for (int x = 0; x < n; ++x) {
+            float ndv = ((float)x + 0.5f) / (float)n;
+            float th = acosf(ndv);
+            host[2 * x] = cosf(th); host[2 * x + 1] = sinf(th);
+        }
+        t.count = n;
+    }
+    size_t bytes = host.size() * sizeof(float);
+    if (bytes < 16) bytes = 16;
+    hipError_t e = hipMalloc(&t.dev, bytes);
+    if (e != hipSuccess) { gpu_fail("table allocation failed: %s", hipGetErrorString(e)); return nullptr; }
+    HIP_OK(hipMemcpy(t.dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    auto ins = G.tables.insert({key, t});
+    return &ins.first->second;
+}
+
+// ------------------------------------------------------------------------------------------
+// graphs
+// ------------------------------------------------------------------------------------------
+GPU_API GPU_Graph* GPU_MakeGraph(void) {
+    GPU_REQUIRE(G.init, nullptr, "GPU_MakeGraph: GPU_Init has not been called");
+    GPU_Graph* g = new GPU_Graph();
+    HIP_OK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    return g;
+}
+GPU_API void GPU_MakeSwapchainGraphs(uint32_t count, GPU_Graph** out) {
+    for (uint32_t i = 0; i < count; ++i) out[i] = GPU_MakeGraph();
+}
+GPU_API GPU_Texture* GPU_GetBackbuffer(GPU_Graph* g) { (void)g; return nullptr; }
+GPU_API void* GPUX_GraphStream(GPU_Graph* g) { return g ? (void*)g->stream : nullptr; }
+
+static void reset_graph(GPU_Graph* g) {
+    g->ops.clear();
+    g->submitted = false;
+    g->bound_cpipe = nullptr; g->bound_cset = nullptr; g->push_size = 0;
+    g->preparing = nullptr; g->in_pass = nullptr; g->draw_params.clear(); g->bound_draw = -1;
+}
+GPU_API void GPU_DestroyGraph(GPU_Graph* g) {
+    GPU_REQUIRE_V(g, "GPU_DestroyGraph: NULL graph");            // the reference does not accept NULL here (gpu_vulkan.c:2393-2404)
+    hipStreamSynchronize(g->stream);
+    for (hipEvent_t e : g->ev) hipEventDestroy(e);
+    hipStreamDestroy(g->stream);
+    delete g;
+}
+
+#define REC_GUARD(g) GPU_REQUIRE_V((g) && !(g)->submitted, "%s: graph is NULL or already submitted (call GPU_GraphWait first)", __func__)
+
+GPU_API void GPU_OpBindComputePipeline(GPU_Graph* g, GPU_ComputePipeline* p) { REC_GUARD(g); g->bound_cpipe = p; }
+GPU_API void GPU_OpBindComputeDescriptorSet(GPU_Graph* g, GPU_DescriptorSet* s) {
+    REC_GUARD(g);
+    GPU_REQUIRE_V(s && s->finalized, "GPU_OpBindComputeDescriptorSet: set is NULL or not finalised");
+    g->bound_cset = s;
+}
+static void push_constants(GPU_Graph* g, void* data, uint32_t size, const char* fn) {
+    GPU_REQUIRE_V(g && !g->submitted, "%s: graph is NULL or already submitted", fn);
+    GPU_REQUIRE_V(size <= 128 && (data || size == 0), "%s: at most 128 bytes of push constants (gpu_vulkan.c:710)", fn);
+    memcpy(g->push, data, size);
+    g->push_size = size;
+}
+GPU_API void GPU_OpPushComputeConstants(GPU_Graph* g, GPU_PipelineLayout* l, void* data, uint32_t size) { (void)l; push_constants(g, data, size, __func__); }
+GPU_API void GPU_OpPushGraphicsConstants(GPU_Graph* g, GPU_PipelineLayout* l, void* data, uint32_t size) { (void)l; push_constants(g, data, size, __func__); }
+
+static Slot* named_slot(GPU_DescriptorSet* set, const char* name) {
+    int b = find_binding(set->layout, name);
+    return b < 0 ? nullptr : &set->slots[b];
+}
+
+// Validates a dispatch against the bound pipeline/set at record time, so that nothing can fault at launch.
+static bool record_dispatch(GPU_Graph* g, Op& op, const char* fn) {
+    GPU_REQUIRE(g->bound_cpipe, false, "%s: no compute pipeline bound", fn);
+    GPU_REQUIRE(g->bound_cset, false, "%s: no compute descriptor set bound", fn);
+    GPU_REQUIRE(g->bound_cset->layout == g->bound_cpipe->layout, false, "%s: descriptor set and pipeline use different layouts", fn);
+    op.kind = Op_Dispatch;
+    op.cpipe = g->bound_cpipe; op.set = g->bound_cset;
+    memcpy(op.push, g->push, g->push_size); op.push_size = g->push_size;
+    Slot* out = named_slot(op.set, "OUTPUT");
+    GPU_REQUIRE(out && out->tex, false, "%s: OUTPUT is not bound", fn);
+    TextureImpl* ot = out->tex;
+    if (op.cpipe->kernel == Kernel_BrdfLut) {
+        GPU_REQUIRE(ot->base.layer_count == 1 && ot->base.width == ot->base.height, false, "%s: BRDF LUT output must be a square 2D image", fn);
+        GPU_REQUIRE(ot->base.format == GPU_Format_RG16F || ot->base.format == GPU_Format_RG32F || ot->base.format == GPU_Format_RGBA32F, false,
+                    "%s: BRDF LUT output format must be RG16F, RG32F or RGBA32F", fn);
+    } else {
+        GPU_REQUIRE(is_f4_cube(ot), false, "%s: OUTPUT must be a square RGBA32F cubemap", fn);
+        Slot* env = named_slot(op.set, "TEX_ENV_CUBE");
+        GPU_REQUIRE(env && env->tex && is_f4_cube(env->tex), false, "%s: TEX_ENV_CUBE must be a square RGBA32F cubemap", fn);
+        GPU_REQUIRE(env->tex != ot, false, "%s: TEX_ENV_CUBE and OUTPUT alias", fn);
+    }
+    return true;
+}
+
+GPU_API void GPU_OpDispatch(GPU_Graph* g, uint32_t gx, uint32_t gy, uint32_t gz) {
+    REC_GUARD(g);
+    GPU_REQUIRE_V(g->in_pass == nullptr, "GPU_OpDispatch: inside a render pass");
+    GPU_REQUIRE_V(gx > 0 && gy > 0 && gz > 0, "GPU_OpDispatch: zero group count");
+    Op op;
+    if (!record_dispatch(g, op, __func__)) return;
+    op.gx = gx; op.gy = gy; op.gz = gz;
+    Slot* out = named_slot(op.set, "OUTPUT");
+    uint32_t size = mip_dim(out->tex->base.width, out->mip);
+    // local size is 8x8x6 (shader line 1): the kernels work on whole rows, so the x extent must cover the image
+    GPU_REQUIRE_V(gx * 8 >= size, "GPU_OpDispatch: partial-width dispatch (%u groups over %u texels) is unsupported", gx, size);
+    op.face0 = 0; op.face1 = out->tex->base.layer_count;
+    op.row0 = 0; op.row1 = gy * 8 < size ? gy * 8 : size;
+    g->ops.push_back(op);
+}
+
+GPU_API void GPUX_OpDispatchRows(GPU_Graph* g, uint32_t face0, uint32_t face1, uint32_t row0, uint32_t row1) {
+    REC_GUARD(g);
+    GPU_REQUIRE_V(g->in_pass == nullptr, "GPUX_OpDispatchRows: inside a render pass");
+    Op op;
+    if (!record_dispatch(g, op, __func__)) return;
+    Slot* out = named_slot(op.set, "OUTPUT");
+    uint32_t size = mip_dim(out->tex->base.width, out->mip);
+    GPU_REQUIRE_V(face0 < face1 && face1 <= out->tex->base.layer_count && row0 < row1 && row1 <= size,
+                  "GPUX_OpDispatchRows: range faces [%u,%u) rows [%u,%u) outside a %u-layer %ux%u image", face0, face1, row0, row1,
+                  out->tex->base.layer_count, size, size);
+    op.face0 = face0; op.face1 = face1; op.row0 = row0; op.row1 = row1; op.rows_explicit = true;
+    g->ops.push_back(op);
+}
+
+// ---- render-pass vocabulary (lighting pass only) ----
+GPU_API void GPU_OpPrepareRenderPass(GPU_Graph* g, GPU_RenderPass* rp) {
+    REC_GUARD(g);
+    GPU_REQUIRE_V(rp && g->preparing == nullptr && g->in_pass == nullptr, "GPU_OpPrepareRenderPass: bad state");   // gpu_vulkan.c:2957
+    g->preparing = rp;
+    g->draw_params.clear();
+}
+GPU_API uint32_t GPU_OpPrepareDrawParams(GPU_Graph* g, GPU_GraphicsPipeline* p, GPU_DescriptorSet* s) {
+    GPU_REQUIRE(g && g->preparing, 0, "GPU_OpPrepareDrawParams: no render pass is being prepared");              // :2964
+    GPU_REQUIRE(p && s && s->finalized, 0, "GPU_OpPrepareDrawParams: NULL pipeline / unfinalised set");
+    g->draw_params.push_back({p, s});
+    return (uint32_t)g->draw_params.size() - 1;
+}
+GPU_API void GPU_OpBeginRenderPass(GPU_Graph* g) {
+    REC_GUARD(g);
+    GPU_REQUIRE_V(g->preparing, "GPU_OpBeginRenderPass: GPU_OpPrepareRenderPass was not called");
+    g->in_pass = g->preparing; g->preparing = nullptr; g->bound_draw = -1;
+}
+GPU_API void GPU_OpEndRenderPass(GPU_Graph* g) {
+    REC_GUARD(g);
+    GPU_REQUIRE_V(g->in_pass, "GPU_OpEndRenderPass: not inside a render pass");
+    g->in_pass = nullptr; g->bound_draw = -1;
+}
+GPU_API void GPU_OpBindDrawParams(GPU_Graph* g, uint32_t idx) {
+    REC_GUARD(g);
+    GPU_REQUIRE_V(g->in_pass && idx < g->draw_params.size(), "GPU_OpBindDrawParams: bad state / index");
+    g->bound_draw = (int)idx;
+}
+
+static bool check_plane(Slot* s, GPU_Format f, uint32_t w, uint32_t h, const char* name) {
+    GPU_REQUIRE(s && s->tex, false, "lighting pass: \"%s\" is not bound", name);
+    GPU_REQUIRE(s->tex->base.format == f && s->tex->base.width == w && s->tex->base.height == h && s->tex->base.layer_count == 1, false,
+                "lighting pass: \"%s\" must be a %ux%u 2D texture of format %d", name, w, h, (int)f);
+    return true;
+}
+
+static void record_shade(GPU_Graph* g, uint32_t row0, uint32_t row1, bool explicit_rows, const char* fn) {
+    GPU_REQUIRE_V(g->in_pass && g->bound_draw >= 0, "%s: no draw params bound inside a render pass", fn);
+    DrawParams dp = g->draw_params[g->bound_draw];
+    GPU_REQUIRE_V(dp.pipeline->kernel == Kernel_Lighting, "%s: unsupported (raster)", fn);
+    GPU_REQUIRE_V(dp.pipeline->pass == g->in_pass, "%s: pipeline was created for a different render pass", fn);
+    GPU_REQUIRE_V(dp.set->layout == dp.pipeline->layout, "%s: descriptor set and pipeline use different layouts", fn);
+    GPU_RenderPass* rp = g->in_pass;
+    uint32_t W = rp->desc.width, H = rp->desc.height;
+    GPU_REQUIRE_V(rp->targets.size() == 1 && rp->targets[0].texture, "%s: lighting pass needs one colour target", fn);
+    TextureImpl* target = (TextureImpl*)rp->targets[0].texture;
+    GPU_REQUIRE_V((target->base.format == GPU_Format_RGBA16F || target->base.format == GPU_Format_RGBA32F) &&
+                  target->base.width == W && target->base.height == H, "%s: colour target must be %ux%u RGBA16F/RGBA32F", fn, W, H);
+    GPU_DescriptorSet* s = dp.set;
+    if (!check_plane(named_slot(s, "GBUFFER_BASE_COLOR"), GPU_Format_RGBA8UN, W, H, "GBUFFER_BASE_COLOR")) return;
+    if (!check_plane(named_slot(s, "GBUFFER_NORMAL"), GPU_Format_RGBA8UN, W, H, "GBUFFER_NORMAL")) return;
+    if (!check_plane(named_slot(s, "GBUFFER_ORM"), GPU_Format_RGBA8UN, W, H, "GBUFFER_ORM")) return;
+    if (!check_plane(named_slot(s, "GBUFFER_EMISSIVE"), GPU_Format_RGBA8UN, W, H, "GBUFFER_EMISSIVE")) return;
+    if (!check_plane(named_slot(s, "GBUFFER_DEPTH"), GPU_Format_D32F_Or_X8D24UN, W, H, "GBUFFER_DEPTH")) return;
+    Slot* gl = named_slot(s, "GLOBALS");
+    GPU_REQUIRE_V(gl && gl->buf && gl->buf->base.size >= 552, "%s: \"GLOBALS\" must be a buffer of at least 552 bytes (render.h:122-136)", fn);
+    Slot* pre = named_slot(s, "PREFILTERED_ENV_MAP");
+    GPU_REQUIRE_V(pre && pre->tex && is_f4_cube(pre->tex), "%s: \"PREFILTERED_ENV_MAP\" must be a square RGBA32F cubemap", fn);
+    if (dp.pipeline->shade_flags & GPUX_Shade_IBL) {
+        Slot* irr = named_slot(s, "TEX_IRRADIANCE_MAP");
+        GPU_REQUIRE_V(irr && irr->tex && is_f4_cube(irr->tex), "%s: \"TEX_IRRADIANCE_MAP\" must be a square RGBA32F cubemap", fn);
+        Slot* lut = named_slot(s, "BRDF_INTEGRATION_MAP");
+        GPU_REQUIRE_V(lut && lut->tex && lut->tex->base.format == GPU_Format_RG16F && lut->tex->base.width == lut->tex->base.height,
+                      "%s: \"BRDF_INTEGRATION_MAP\" must be a square RG16F texture", fn);
+    }
+    Op op;
+    op.kind = Op_Shade;
+    op.gpipe = dp.pipeline; op.set = s; op.pass = rp;
+    op.row0 = explicit_rows ? row0 : 0; op.row1 = explicit_rows ? row1 : H;
+    GPU_REQUIRE_V(op.row0 < op.row1 && op.row1 <= H, "%s: rows [%u,%u) outside the %u-row pass", fn, op.row0, op.row1, H);
+    g->ops.push_back(op);
+}
+
+GPU_API void GPU_OpDraw(GPU_Graph* g, uint32_t vertex_count, uint32_t instance_count, uint32_t first_vertex, uint32_t first_instance) {
+    REC_GUARD(g);
+    GPU_REQUIRE_V(vertex_count == 3 && instance_count == 1 && first_vertex == 0 && first_instance == 0,
+                  "GPU_OpDraw: unsupported (raster): only the full-screen triangle GPU_OpDraw(3,1,0,0) of the lighting pass is implemented");
+    record_shade(g, 0, 0, false, __func__);
+}
+GPU_API void GPUX_OpDrawRows(GPU_Graph* g, uint32_t row0, uint32_t row1) { REC_GUARD(g); record_shade(g, row0, row1, true, __func__); }
+GPU_API void GPU_OpDrawIndexed(GPU_Graph* g, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) { (void)g; gpu_fail("GPU_OpDrawIndexed: unsupported (raster)"); }
+GPU_API void GPU_OpBindVertexBuffer(GPU_Graph* g, GPU_Buffer* b) { (void)g; (void)b; gpu_fail("GPU_OpBindVertexBuffer: unsupported (raster)"); }
+GPU_API void GPU_OpBindIndexBuffer(GPU_Graph* g, GPU_Buffer* b) { (void)g; (void)b; gpu_fail("GPU_OpBindIndexBuffer: unsupported (raster)"); }
+
+// ---- transfers ----
+GPU_API void GPU_OpCopyBufferToBuffer(GPU_Graph* g, GPU_Buffer* src, GPU_Buffer* dst, uint32_t dst_offset, uint32_t src_offset, uint32_t size) {
+    REC_GUARD(g);
+    GPU_REQUIRE_V(g->in_pass == nullptr, "GPU_OpCopyBufferToBuffer: inside a render pass");
+    GPU_REQUIRE_V(src && dst && (uint64_t)src_offset + size <= src->size && (uint64_t)dst_offset + size <= dst->size, "GPU_OpCopyBufferToBuffer: range out of bounds");
+    Op op; op.kind = Op_CopyB2B; op.name = "copy.buffer_to_buffer";
+    op.buf = (BufferImpl*)src; op.buf2 = (BufferImpl*)dst; op.off_a = src_offset; op.off_b = dst_offset; op.size = size;
+    g->ops.push_back(op);
+}
+GPU_API void GPU_OpCopyBufferToTexture(GPU_Graph* g, GPU_Buffer* src, GPU_Texture* dst, uint32_t first_layer, uint32_t layer_count, uint32_t mip) {
+    REC_GUARD(g);
+    GPU_REQUIRE_V(g->in_pass == nullptr, "GPU_OpCopyBufferToTexture: inside a render pass");
+    GPU_REQUIRE_V(src && dst && mip < dst->mip_level_count && layer_count > 0 && first_layer + layer_count <= dst->layer_count, "GPU_OpCopyBufferToTexture: bad subresource");
+    uint64_t per_layer = GPUX_TextureMipBytes(dst, mip) / dst->layer_count;
+    GPU_REQUIRE_V(per_layer * layer_count <= src->size, "GPU_OpCopyBufferToTexture: buffer too small (%u < %llu)", src->size, (unsigned long long)(per_layer * layer_count));
+    Op op; op.kind = Op_CopyB2T; op.name = "copy.buffer_to_texture";
+    op.buf = (BufferImpl*)src; op.tex = (TextureImpl*)dst; op.mip = mip; op.layer0 = first_layer; op.layer_count = layer_count; op.off_a = 0;
+    g->ops.push_back(op);
+}
+GPU_API void GPUX_OpCopyBufferToTextureMip(GPU_Graph* g, GPU_Buffer* src, uint32_t src_offset, GPU_Texture* dst, uint32_t mip) {
+    REC_GUARD(g);
+    GPU_REQUIRE_V(src && dst && mip < dst->mip_level_count, "GPUX_OpCopyBufferToTextureMip: bad arguments");
+    GPU_REQUIRE_V((uint64_t)src_offset + GPUX_TextureMipBytes(dst, mip) <= src->size, "GPUX_OpCopyBufferToTextureMip: buffer too small");
+    Op op; op.kind = Op_CopyB2T; op.name = "copy.buffer_to_texture";
+    op.buf = (BufferImpl*)src; op.tex = (TextureImpl*)dst; op.mip = mip; op.layer0 = 0; op.layer_count = dst->layer_count; op.off_a = src_offset;
+    g->ops.push_back(op);
+}
+static void record_t2b(GPU_Graph* g, GPU_Texture* src, uint32_t mip, GPU_Buffer* dst, uint32_t dst_offset, const char* fn) {
+    GPU_REQUIRE_V(g->in_pass == nullptr, "%s: inside a render pass", fn);
+    GPU_REQUIRE_V(src && dst && mip < src->mip_level_count, "%s: bad arguments", fn);
+    GPU_REQUIRE_V((uint64_t)dst_offset + GPUX_TextureMipBytes(src, mip) <= dst->size, "%s: buffer too small (%u bytes for %llu)", fn, dst->size,
+                  (unsigned long long)GPUX_TextureMipBytes(src, mip));
+    Op op; op.kind = Op_CopyT2B; op.name = "copy.texture_to_buffer";
+    op.tex = (TextureImpl*)src; op.mip = mip; op.buf = (BufferImpl*)dst; op.off_b = dst_offset;
+    g->ops.push_back(op);
+}
+GPU_API void GPU_OpCopyTextureToBuffer(GPU_Graph* g, GPU_Texture* src, GPU_Buffer* dst) { REC_GUARD(g); record_t2b(g, src, 0, dst, 0, __func__); }   // mip 0 only (gpu_vulkan.c:2948)
+GPU_API void GPUX_OpCopyTextureMipToBuffer(GPU_Graph* g, GPU_Texture* src, uint32_t mip, GPU_Buffer* dst, uint32_t off) { REC_GUARD(g); record_t2b(g, src, mip, dst, off, __func__); }
+
+GPU_API void GPU_OpGenerateMipmaps(GPU_Graph* g, GPU_Texture* tex) {
+    REC_GUARD(g);
+    GPU_REQUIRE_V(tex, "GPU_OpGenerateMipmaps: NULL texture");
+    TextureImpl* t = (TextureImpl*)tex;
+    GPU_REQUIRE_V(is_f4_cube(t) && !(tex->width & (tex->width - 1)), "GPU_OpGenerateMipmaps: implemented for power-of-two RGBA32F cubemaps only");
+    Op op; op.kind = Op_MipGen; op.name = "K2.mip_chain"; op.tex = t;
+    g->ops.push_back(op);
+}
+GPU_API void GPU_OpBlit(GPU_Graph* g, const GPU_OpBlitInfo* info) {
+    REC_GUARD(g);
+    GPU_REQUIRE_V(g->in_pass == nullptr, "GPU_OpBlit: inside a render pass");                                        // gpu_vulkan.c:2787
+    GPU_REQUIRE_V(info && info->src_texture && info->dst_texture, "GPU_OpBlit: NULL argument");
+    const GPU_Texture* s = info->src_texture; const GPU_Texture* d = info->dst_texture;
+    if (s == d) GPU_REQUIRE_V(info->dst_mip_level != info->src_mip_level || info->src_layer != info->dst_layer, "GPU_OpBlit: blit of a subresource onto itself");   // :2792
+    GPU_REQUIRE_V(s->format == GPU_Format_RGBA32F && d->format == GPU_Format_RGBA32F && info->filter == GPU_Filter_Linear, "GPU_OpBlit: RGBA32F linear blits only");
+    GPU_REQUIRE_V(info->src_mip_level < s->mip_level_count && info->dst_mip_level < d->mip_level_count && info->src_layer < s->layer_count && info->dst_layer < d->layer_count,
+                  "GPU_OpBlit: bad subresource");
+    uint32_t sw = mip_dim(s->width, info->src_mip_level), sh = mip_dim(s->height, info->src_mip_level);
+    uint32_t dw = mip_dim(d->width, info->dst_mip_level), dh = mip_dim(d->height, info->dst_mip_level);
+    bool full = info->src_area[0].x == 0 && info->src_area[0].y == 0 && info->dst_area[0].x == 0 && info->dst_area[0].y == 0 &&
+                (uint32_t)info->src_area[1].x == sw && (uint32_t)info->src_area[1].y == sh && (uint32_t)info->dst_area[1].x == dw && (uint32_t)info->dst_area[1].y == dh;
+    GPU_REQUIRE_V(full && sw == sh && dw == dh && sw == 2 * dw, "GPU_OpBlit: only whole-subresource exact 2:1 square blits are implemented");
+    Op op; op.kind = Op_Blit; op.name = "K2.blit_2to1";
+    op.tex = (TextureImpl*)s; op.tex2 = (TextureImpl*)d; op.mip = info->src_mip_level; op.mip2 = info->dst_mip_level;
+    op.layer0 = info->src_layer; op.layer2 = info->dst_layer;
+    g->ops.push_back(op);
+}
+static void record_clear(GPU_Graph* g, GPU_Texture* dst, uint32_t mip, int mode, const float* f, const uint32_t* u, const char* fn) {
+    GPU_REQUIRE_V(g->in_pass == nullptr, "%s: inside a render pass", fn);
+    GPU_REQUIRE_V(dst && (mip == GPU_MIP_LEVEL_ALL || mip < dst->mip_level_count), "%s: bad texture / mip", fn);
+    Op op; op.kind = Op_Clear; op.name = "clear"; op.tex = (TextureImpl*)dst; op.mip = mip; op.clear_mode = mode;
+    for (int i = 0; i < 4; ++i) { op.clear[i] = f ? f[i] : 0.0f; op.cleari[i] = u ? u[i] : 0; }
+    g->ops.push_back(op);
+}
+GPU_API void GPU_OpClearColorF(GPU_Graph* g, GPU_Texture* dst, uint32_t mip, float r, float gg, float b, float a) {
+    REC_GUARD(g); float f[4] = {r, gg, b, a}; record_clear(g, dst, mip, 0, f, nullptr, __func__);
+}
+GPU_API void GPU_OpClearColorI(GPU_Graph* g, GPU_Texture* dst, uint32_t mip, uint32_t r, uint32_t gg, uint32_t b, uint32_t a) {
+    REC_GUARD(g); uint32_t u[4] = {r, gg, b, a}; record_clear(g, dst, mip, 1, nullptr, u, __func__);
+}
+GPU_API void GPU_OpClearDepthStencil(GPU_Graph* g, GPU_Texture* dst, uint32_t mip) {
+    REC_GUARD(g);
+    GPU_REQUIRE_V(dst && GPUX_GetFormatInfo(dst->format).depth_target, "GPU_OpClearDepthStencil: not a depth format");   // gpu_vulkan.c:2875
+    float f[4] = {1.0f, 0, 0, 0}; record_clear(g, dst, mip, 2, f, nullptr, __func__);                                    // GPU_REVERSE_DEPTH false -> far = 1
+}
+
+// ------------------------------------------------------------------------------------------
+// execution
+// ------------------------------------------------------------------------------------------
+static bool ensure_bordered(TextureImpl* t, hipStream_t st) {
+    if (t->bordered_valid) return true;
+    int W = (int)t->base.width, levels = (int)t->base.mip_level_count;
+    if (!t->bordered) {
+        t->bordered_bytes = pbrk_bordered_pyramid_texels(W, levels) * 16;
+        hipError_t e = hipMalloc(&t->bordered, t->bordered_bytes);
+        if (e != hipSuccess) { gpu_fail("bordered twin allocation (%zu bytes) failed: %s", t->bordered_bytes, hipGetErrorString(e)); return false; }
+    }
+    int rc = pbrk_border_build(t->dev, t->bordered, W, levels, st);
+    if (rc != PBRK_OK) { gpu_fail("border build failed (%d)", rc); return false; }
+    t->bordered_valid = true;
+    return true;
+}
+
+static float reference_roughness(int mip) {                      // gen_prefiltered_env_map.glsl:117 + SURVEY 8d extension
+    static const float tab[5] = {0.0f, 0.03f, 0.15f, 0.4f, 0.6f};
+    if (mip < 5) return tab[mip < 0 ? 0 : mip];
+    float r = 0.6f + 0.08f * (float)(mip - 4);
+    return r > 1.0f ? 1.0f : r;
+}
+
+static hipEvent_t next_event(GPU_Graph* g, size_t& used) {
+    if (used == g->ev.size()) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); g->ev.push_back(e); }
+    return g->ev[used++];
+}
+
+// Runs `launch` bracketed by events when timing is on.
+template <class F>
+static void timed(GPU_Graph* g, const std::string& name, size_t& ev_used, F launch) {
+    if (G.timing) {
+        hipEvent_t a = next_event(g, ev_used);
+        HIP_OK(hipEventRecord(a, g->stream));
+        launch();
+        hipEvent_t b = next_event(g, ev_used);
+        HIP_OK(hipEventRecord(b, g->stream));
+        g->timed_names.push_back(name);
+    } else {
+        launch();
+    }
+}
+
+static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
+    hipStream_t st = g->stream;
+    switch (op.kind) {
+    case Op_Dispatch: {
+        Slot* out = named_slot(op.set, "OUTPUT");
+        TextureImpl* ot = out->tex;
+        uint32_t size = mip_dim(ot->base.width, out->mip);
+        void* out_ptr = (char*)ot->dev + ot->mip_offset[out->mip];
+        GPUX_IBLConstants c = {0, 0.0f, 0.0f, 0};
+        bool explicit_c = false;
+        if (op.push_size == sizeof(GPUX_IBLConstants)) { memcpy(&c, op.push, sizeof c); explicit_c = true; }
+        else if (op.push_size >= 4) memcpy(&c.mip_level, op.push, 4);
+        char nm[96];
+        if (op.cpipe->kernel == Kernel_BrdfLut) {
+            int n = (explicit_c && c.sample_count > 0) ? c.sample_count : 4096;
+            DeviceTable* ang = get_table(2, n, 0.0f, 0);
+            DeviceTable* vcs = get_table(3, (int)size, 0.0f, 0);
+            if (!ang || !vcs) return;
+            int fmt = ot->base.format == GPU_Format_RG16F ? PBRK_FMT_RG16F : (ot->base.format == GPU_Format_RG32F ? PBRK_FMT_RG32F : PBRK_FMT_RGBA32F);
+            timed(g, "K1.brdf_lut", ev_used, [&] {
+                int rc = pbrk_brdf_lut(out_ptr, fmt, (int)size, n, ang->dev, vcs->dev, (int)op.row0, (int)op.row1, st);
+                if (rc != PBRK_OK) gpu_fail("K1 launch failed (%d)", rc);
+            });
+            ot->bordered_valid = false;
+            return;
+        }
+        Slot* env = named_slot(op.set, "TEX_ENV_CUBE");
+        TextureImpl* et = env->tex;
+        if (!et->bordered_valid) {
+            timed(g, "apron.env", ev_used, [&] { ensure_bordered(et, st); });
+            if (!et->bordered_valid) return;
+        }
+        int W = (int)et->base.width, levels = (int)et->base.mip_level_count;
+        float lod; int n; float divisor, alpha = 0.0f; DeviceTable* tab = nullptr;
+        bool copy = false;
+        if (op.cpipe->kernel == Kernel_Prefilter) {
+            int mip = c.mip_level;
+            if (mip == 0) { copy = true; lod = explicit_c ? c.src_lod : 1.0f; }
+            else {
+                lod = explicit_c ? c.src_lod : 3.0f + (float)mip;
+                n = (explicit_c && c.sample_count > 0) ? c.sample_count : 8192;
+                float rough = explicit_c ? c.roughness : reference_roughness(mip);
+                if (!(rough > 0.0f)) { gpu_fail("prefilter: roughness must be > 0 for Monte-Carlo mips (got %g)", rough); return; }
+                tab = get_table(0, n, rough, 0);
+                if (!tab) return;
+                divisor = 3.14159265358979323846f; alpha = tab->alpha;
+            }
+            snprintf(nm, sizeof nm, copy ? "K4a.prefilter_copy.mip%d" : "K4b.prefilter_mc.mip%d", mip);
+        } else {
+            lod = explicit_c ? c.src_lod : 6.0f;                 // gen_irradiance_map.glsl:94
+            n = (explicit_c && c.sample_count > 0) ? c.sample_count : 1024;
+            tab = get_table(1, n, 0.0f, 0);
+            if (!tab) return;
+            divisor = (float)n; alpha = 0.0f;
+            snprintf(nm, sizeof nm, "K3.irradiance");
+        }
+        int l = (int)floorf(lod);
+        if (l < 0) l = 0;
+        if (l > levels - 1) l = levels - 1;                     // sampler clamps LOD to the chain
+        if ((float)l != lod && lod < (float)(levels - 1)) { gpu_fail("%s: fractional source LOD %g is not supported by the precompute kernels", nm, lod); return; }
+        int n_src = W >> l; if (n_src < 1) n_src = 1;
+        const void* src = (const char*)et->bordered + pbrk_bordered_level_offset(W, l) * 16;
+        timed(g, nm, ev_used, [&] {
+            int rc = copy ? pbrk_prefilter_copy(src, n_src, out_ptr, (int)size, (int)op.face0, (int)op.face1, (int)op.row0, (int)op.row1, st)
+                          : pbrk_mc_filter(src, n_src, tab->dev, tab->count, divisor, alpha, out_ptr, (int)size,
+                                           (int)op.face0, (int)op.face1, (int)op.row0, (int)op.row1, st);
+            if (rc != PBRK_OK) gpu_fail("%s launch failed (%d)", nm, rc);
+        });
+        ot->bordered_valid = false;
+        return;
+    }
+    case Op_Shade: {
+        GPU_DescriptorSet* s = op.set;
+        GPU_RenderPass* rp = op.pass;
+        TextureImpl* target = (TextureImpl*)rp->targets[0].texture;
+        PbrkShadeArgs a;
+        memset(&a, 0, sizeof a);
+        a.width = (int)rp->desc.width; a.height = (int)rp->desc.height;
+        a.x0 = 0; a.x1 = a.width; a.y0 = (int)op.row0; a.y1 = (int)op.row1;
+        a.base_color = named_slot(s, "GBUFFER_BASE_COLOR")->tex->dev;
+        a.normal = named_slot(s, "GBUFFER_NORMAL")->tex->dev;
+        a.orm = named_slot(s, "GBUFFER_ORM")->tex->dev;
+        a.emissive = named_slot(s, "GBUFFER_EMISSIVE")->tex->dev;
+        a.depth = named_slot(s, "GBUFFER_DEPTH")->tex->dev;
+        TextureImpl* pre = named_slot(s, "PREFILTERED_ENV_MAP")->tex;
+        if (!pre->bordered_valid) { timed(g, "apron.prefiltered", ev_used, [&] { ensure_bordered(pre, g->stream); }); if (!pre->bordered_valid) return; }
+        a.prefiltered_bordered = pre->bordered; a.prefiltered_size = (int)pre->base.width; a.prefiltered_levels = (int)pre->base.mip_level_count;
+        a.flags = 0;
+        if (op.gpipe->shade_flags & GPUX_Shade_IBL) {
+            a.flags |= PBRK_SHADE_IBL;
+            TextureImpl* irr = named_slot(s, "TEX_IRRADIANCE_MAP")->tex;
+            if (!irr->bordered_valid) { timed(g, "apron.irradiance", ev_used, [&] { ensure_bordered(irr, g->stream); }); if (!irr->bordered_valid) return; }
+            a.irradiance_bordered = irr->bordered; a.irradiance_size = (int)irr->base.width;
+            TextureImpl* lut = named_slot(s, "BRDF_INTEGRATION_MAP")->tex;
+            a.lut = lut->dev; a.lut_size = (int)lut->base.width;
+        }
+        if (op.gpipe->shade_flags & GPUX_Shade_LightShafts) a.flags |= PBRK_SHADE_SHAFTS;
+        a.out = target->dev;
+        a.out_format = target->base.format == GPU_Format_RGBA16F ? PBRK_FMT_RGBA16F : PBRK_FMT_RGBA32F;
+        BufferImpl* gb = named_slot(s, "GLOBALS")->buf;
+        // Globals snapshot at submit time: the caller fills the persistently mapped buffer before GPU_GraphSubmit (render.cpp:991)
+        if (gb->pinned_host) memcpy(a.globals, gb->dev, 552);
+        else HIP_OK(hipMemcpy(a.globals, gb->dev, 552, hipMemcpyDeviceToHost));
+        timed(g, "K5.shade", ev_used, [&] {
+            int rc = pbrk_shade(&a, st);
+            if (rc != PBRK_OK) gpu_fail("K5 launch failed (%d)", rc);
+        });
+        target->bordered_valid = false;
+        return;
+    }
+    case Op_MipGen: {
+        timed(g, op.name, ev_used, [&] {
+            int rc = pbrk_mip_chain(op.tex->dev, (int)op.tex->base.width, (int)op.tex->base.mip_level_count, st);
+            if (rc != PBRK_OK) gpu_fail("K2 launch failed (%d)", rc);
+        });
+        op.tex->bordered_valid = false;
+        return;
+    }
+    case Op_Blit: {
+        uint32_t ns = mip_dim(op.tex->base.width, op.mip);
+        size_t layer_bytes_s = (size_t)ns * ns * 16, layer_bytes_d = layer_bytes_s / 4;
+        const void* src = (const char*)op.tex->dev + op.tex->mip_offset[op.mip] + layer_bytes_s * op.layer0;
+        void* dst = (char*)op.tex2->dev + op.tex2->mip_offset[op.mip2] + layer_bytes_d * op.layer2;
+        timed(g, op.name, ev_used, [&] {
+            int rc = pbrk_box_downsample(src, (int)ns, dst, 1, st);
+            if (rc != PBRK_OK) gpu_fail("blit launch failed (%d)", rc);
+        });
+        op.tex2->bordered_valid = false;
+        return;
+    }
+    case Op_CopyB2B:
+        timed(g, op.name, ev_used, [&] { HIP_OK(hipMemcpyAsync((char*)op.buf2->dev + op.off_b, (const char*)op.buf->dev + op.off_a, op.size, hipMemcpyDefault, st)); });
+        return;
+    case Op_CopyB2T: {
+        uint64_t per_layer = GPUX_TextureMipBytes(&op.tex->base, op.mip) / op.tex->base.layer_count;
+        timed(g, op.name, ev_used, [&] {
+            HIP_OK(hipMemcpyAsync((char*)op.tex->dev + op.tex->mip_offset[op.mip] + per_layer * op.layer0, (const char*)op.buf->dev + op.off_a,
+                                  per_layer * op.layer_count, hipMemcpyDefault, st));
+        });
+        op.tex->bordered_valid = false;
+        return;
+    }
+    case Op_CopyT2B:
+        timed(g, op.name, ev_used, [&] {
+            HIP_OK(hipMemcpyAsync((char*)op.buf->dev + op.off_b, (const char*)op.tex->dev + op.tex->mip_offset[op.mip],
+                                  GPUX_TextureMipBytes(&op.tex->base, op.mip), hipMemcpyDefault, st));
+        });
+        return;
+    case Op_Clear: {
+        TextureImpl* t = op.tex;
+        uint32_t m0 = op.mip == GPU_MIP_LEVEL_ALL ? 0 : op.mip, m1 = op.mip == GPU_MIP_LEVEL_ALL ? t->base.mip_level_count : op.mip + 1;
+        for (uint32_t m = m0; m < m1; ++m) {
+            size_t bytes = (size_t)GPUX_TextureMipBytes(&t->base, m);
+            void* p = (char*)t->dev + t->mip_offset[m];
+            // build one texel pattern on the host and replicate it (clears are rare: upload a staging row)
+            uint32_t tb = t->texel_bytes;
+            std::vector<uint8_t> texel(tb, 0);
+            if (op.clear_mode == 2 || t->base.format == GPU_Format_R32F) { memcpy(texel.data(), &op.clear[0], 4 < tb ? 4 : tb); }
+            else if (op.clear_mode == 1) { for (uint32_t k = 0; k * 4 < tb && k < 4; ++k) memcpy(texel.data() + 4 * k, &op.cleari[k], 4); }
+            else if (t->base.format == GPU_Format_RGBA32F || t->base.format == GPU_Format_RG32F) { memcpy(texel.data(), op.clear, tb); }
+            else if (t->base.format == GPU_Format_RGBA8UN || t->base.format == GPU_Format_BGRA8UN) {
+                int order[4] = {0, 1, 2, 3};
+                if (t->base.format == GPU_Format_BGRA8UN) { order[0] = 2; order[2] = 0; }
+                for (int k = 0; k < 4; ++k) { float v = op.clear[order[k]]; v = v < 0 ? 0 : (v > 1 ? 1 : v); texel[k] = (uint8_t)(v * 255.0f + 0.5f); }
+            } else {
+                bool zero = op.clear[0] == 0 && op.clear[1] == 0 && op.clear[2] == 0 && op.clear[3] == 0;
+                if (!zero) { gpu_fail("GPU_OpClearColorF: non-zero clears of format %d are not implemented", (int)t->base.format); return; }
+            }
+            bool all_same = true;
+            for (uint32_t k = 1; k < tb; ++k) all_same &= texel[k] == texel[0];
+            if (all_same) { HIP_OK(hipMemsetAsync(p, texel[0], bytes, st)); }
+            else if (tb == 4) { uint32_t v; memcpy(&v, texel.data(), 4); HIP_OK(hipMemsetD32Async((hipDeviceptr_t)p, (int)v, bytes / 4, st)); }
+            else {
+                std::vector<uint8_t> host(bytes);
+                for (size_t o = 0; o < bytes; o += tb) memcpy(host.data() + o, texel.data(), tb);
+                HIP_OK(hipMemcpyAsync(p, host.data(), bytes, hipMemcpyHostToDevice, st));
+                HIP_OK(hipStreamSynchronize(st));      // the staging vector dies at scope exit
+            }
+        }
+        t->bordered_valid = false;
+        return;
+    }
+    }
+}
+
+GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
+    GPU_REQUIRE_V(g && !g->submitted, "GPU_GraphSubmit: graph is NULL or already submitted");
+    GPU_REQUIRE_V(g->in_pass == nullptr && g->preparing == nullptr, "GPU_GraphSubmit: render pass still open");
+    g->timed_names.clear(); g->timed_ms.clear();
+    size_t ev_used = 0;
+    for (Op& op : g->ops) exec_op(g, op, ev_used);
+    g->submitted = true;
+}
+
+GPU_API void GPU_GraphWait(GPU_Graph* g) {
+    GPU_REQUIRE_V(g, "GPU_GraphWait: NULL graph");
+    HIP_OK(hipStreamSynchronize(g->stream));
+    g->timed_ms.clear();
+    for (size_t i = 0; i < g->timed_names.size(); ++i) {
+        float ms = 0.0f;
+        HIP_OK(hipEventElapsedTime(&ms, g->ev[2 * i], g->ev[2 * i + 1]));
+        g->timed_ms.push_back(ms);
+    }
+    reset_graph(g);                      // Wait also resets the graph [gpu.h:452]
+}
+
+GPU_API void GPUX_EnableOpTiming(int enable) { G.timing = enable != 0; }
+GPU_API uint32_t GPUX_GraphTimedOpCount(GPU_Graph* g) { return g ? (uint32_t)g->timed_ms.size() : 0; }
+GPU_API const char* GPUX_GraphTimedOpName(GPU_Graph* g, uint32_t i) { return (g && i < g->timed_names.size()) ? g->timed_names[i].c_str() : ""; }
+GPU_API float GPUX_GraphTimedOpMs(GPU_Graph* g, uint32_t i) { return (g && i < g->timed_ms.size()) ? g->timed_ms[i] : 0.0f; }

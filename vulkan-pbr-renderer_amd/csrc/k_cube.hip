@@ -1,0 +1,158 @@
+// k_cube.hip -- bandwidth-shaped cube kernels for gfx950:
+//   K2   mip chain (2x2 box per face)           reference: src/gpu/gpu_vulkan.c:1458-1483, :2786-2826
+//   apron build (seamless-cube bordered layout)  reference: sampler state src/gpu/gpu_vulkan.c:613-634
+//   K4a  prefilter mip 0 = bilinear copy         reference: shaders/gen_prefiltered_env_map.glsl:112-114
+#include "pbr_device.h"
+#include "pbr_kernels.h"
+
+// ------------------------------------------------------------------------------------------
+// K2: one thread per destination texel; each reads two 32-byte row segments and writes 16 bytes.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mip_level(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                   int ns, int nd, int nfaces) {
+    size_t total = (size_t)nfaces * nd * nd;
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
+        int x = (int)(id % nd);
+        size_t r = id / nd;
+        int y = (int)(r % nd);
+        int f = (int)(r / nd);
+        const float4* p = src + ((size_t)f * ns + 2 * y) * ns + 2 * x;
+        float4 a = p[0], b = p[1], c = p[ns], d = p[ns + 1];
+        float4 o;
+        o.x = (((a.x + b.x) + c.x) + d.x) * 0.25f;
+        o.y = (((a.y + b.y) + c.y) + d.y) * 0.25f;
+        o.z = (((a.z + b.z) + c.z) + d.z) * 0.25f;
+        o.w = (((a.w + b.w) + c.w) + d.w) * 0.25f;
+        dst[id] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Apron build.  Edge adjacency of the Vulkan cube faces (table in gen_prefiltered_env_map.glsl:12-23),
+// per face and edge {left i=-1, right i=n, top j=-1, bottom j=n}: neighbour face and how its
+// (i', j') follow from the along-edge index k (0: k, 1: n-1-k, 2: 0, 3: n-1).
+// ------------------------------------------------------------------------------------------
+__constant__ unsigned char kEdge[6][4][3] = {
+    /* +X */ {{4, 3, 0}, {5, 2, 0}, {2, 3, 1}, {3, 3, 0}},
+    /* -X */ {{5, 3, 0}, {4, 2, 0}, {2, 2, 0}, {3, 2, 1}},
+    /* +Y */ {{1, 0, 2}, {0, 1, 2}, {5, 1, 2}, {4, 0, 2}},
+    /* -Y */ {{1, 1, 3}, {0, 0, 3}, {4, 0, 3}, {5, 1, 3}},
+    /* +Z */ {{1, 3, 0}, {0, 2, 0}, {2, 0, 3}, {3, 0, 2}},
+    /* -Z */ {{0, 3, 0}, {1, 2, 0}, {2, 1, 2}, {3, 1, 3}},
+};
+
+__device__ __forceinline__ int edge_code(int code, int k, int n) {
+    return code == 0 ? k : (code == 1 ? n - 1 - k : (code == 2 ? 0 : n - 1));
+}
+
+// texel (i,j) of face f where exactly one of i,j is out of range
+__device__ __forceinline__ float4 edge_texel(const float4* __restrict__ lvl, int n, int f, int i, int j) {
+    int e, k;
+    if (i < 0) { e = 0; k = j; } else if (i >= n) { e = 1; k = j; } else if (j < 0) { e = 2; k = i; } else { e = 3; k = i; }
+    int nf = kEdge[f][e][0];
+    int ni = edge_code(kEdge[f][e][1], k, n);
+    int nj = edge_code(kEdge[f][e][2], k, n);
+    return lvl[((size_t)nf * n + nj) * n + ni];
+}
+
+__global__ __launch_bounds__(256) void k_border_level(const float4* __restrict__ lvl, float4* __restrict__ out, int n) {
+    int nb = n + 2;
+    size_t total = (size_t)6 * nb * nb;
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
+        int bi = (int)(id % nb);
+        size_t r = id / nb;
+        int bj = (int)(r % nb);
+        int f = (int)(r / nb);
+        int i = bi - 1, j = bj - 1;
+        bool oi = (i < 0) | (i >= n), oj = (j < 0) | (j >= n);
+        float4 v;
+        if (!oi && !oj) {
+            v = lvl[((size_t)f * n + j) * n + i];
+        } else if (oi != oj) {
+            v = edge_texel(lvl, n, f, i, j);
+        } else {
+            // cube corner: the missing texel is the mean of the three that exist
+            int ci = i < 0 ? 0 : n - 1, cj = j < 0 ? 0 : n - 1;
+            float4 a = lvl[((size_t)f * n + cj) * n + ci];
+            float4 b = edge_texel(lvl, n, f, i, cj);
+            float4 c = edge_texel(lvl, n, f, ci, j);
+            v.x = ((a.x + b.x) + c.x) / 3.0f;
+            v.y = ((a.y + b.y) + c.y) / 3.0f;
+            v.z = ((a.z + b.z) + c.z) / 3.0f;
+            v.w = ((a.w + b.w) + c.w) / 3.0f;
+        }
+        out[id] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4a: out(face, y, x) = bilinear(src level, R(face, x, y)); 16 B coalesced store per lane.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prefilter_copy(const float4* __restrict__ src, int n_src,
+                                                        float4* __restrict__ out, int size,
+                                                        int face0, int nfaces, int y0, int rows) {
+    size_t total = (size_t)nfaces * rows * size;
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
+        int x = (int)(id % size);
+        size_t r = id / size;
+        int y = y0 + (int)(r % rows);
+        int f = face0 + (int)(r / rows);
+        f3 R = face_texel_dir(f, x, y, size);
+        float4 v = cube_fetch_rgba<true>(src, n_src, R);
+        out[((size_t)f * size + y) * size + x] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+static inline int grid_for(size_t total, int block, int cap) {
+    size_t g = (total + block - 1) / block;
+    if (g > (size_t)cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+static inline int lvl_size(int W, int l) { int n = W >> l; return n < 1 ? 1 : n; }
+
+extern "C" int pbrk_mip_chain(void* pyramid, int W, int levels, void* stream) {
+    if (!pyramid || W <= 0 || levels < 1 || levels > pbrk_mip_count(W, W)) return PBRK_E_ARG;
+    if (W & (W - 1)) return PBRK_E_ARG;    // exact 2:1 chain only
+    float4* base = (float4*)pyramid;
+    for (int l = 1; l < levels; ++l) {
+        int ns = lvl_size(W, l - 1), nd = lvl_size(W, l);
+        const float4* src = base + pbrk_level_offset(W, l - 1);
+        float4* dst = base + pbrk_level_offset(W, l);
+        size_t total = (size_t)6 * nd * nd;
+        hipLaunchKernelGGL(k_mip_level, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, src, dst, ns, nd, 6);
+    }
+    return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+}
+
+extern "C" int pbrk_box_downsample(const void* src, int ns, void* dst, int nlayers, void* stream) {
+    if (!src || !dst || ns < 2 || (ns & 1) || nlayers < 1) return PBRK_E_ARG;
+    int nd = ns / 2;
+    size_t total = (size_t)nlayers * nd * nd;
+    hipLaunchKernelGGL(k_mip_level, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)src, (float4*)dst, ns, nd, nlayers);
+    return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+}
+
+extern "C" int pbrk_border_build(const void* pyramid, void* bordered, int W, int levels, void* stream) {
+    if (!pyramid || !bordered || W <= 0 || levels < 1 || levels > pbrk_mip_count(W, W)) return PBRK_E_ARG;
+    for (int l = 0; l < levels; ++l) {
+        int n = lvl_size(W, l);
+        const float4* src = (const float4*)pyramid + pbrk_level_offset(W, l);
+        float4* dst = (float4*)bordered + pbrk_bordered_level_offset(W, l);
+        size_t total = (size_t)6 * (n + 2) * (n + 2);
+        hipLaunchKernelGGL(k_border_level, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    }
+    return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+}
+
+extern "C" int pbrk_prefilter_copy(const void* src_bordered_level, int n_src, void* out, int out_size,
+                                   int face0, int face1, int y0, int y1, void* stream) {
+    if (!src_bordered_level || !out || n_src < 1 || out_size < 1) return PBRK_E_ARG;
+    if (face0 < 0 || face1 > 6 || face0 >= face1 || y0 < 0 || y1 > out_size || y0 >= y1) return PBRK_E_ARG;
+    size_t total = (size_t)(face1 - face0) * (y1 - y0) * out_size;
+    hipLaunchKernelGGL(k_prefilter_copy, dim3(grid_for(total, 256, 256 * 64)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)src_bordered_level, n_src, (float4*)out, out_size, face0, face1 - face0, y0, y1 - y0);
+    return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+}

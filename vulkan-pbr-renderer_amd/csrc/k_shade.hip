@@ -1,0 +1,229 @@
+// k_shade.hip -- K5: deferred Cook-Torrance shade pass (gfx950).
+//
+// Replaces the fragment stage of shaders/lighting_pass.glsl (main :432-716) as drawn by
+// render.cpp:1119-1127 (full-screen triangle => one invocation per pixel, point fetch of the
+// G-buffer at pixel centres).  In-scope sub-blocks: G-buffer decode :433-442,
+// position reconstruction :444-451, interleaved-gradient noise :456-459, view vector :612-613,
+// F0/kS/kD :657-661, sun term (GGX D :21-31, Mikkelsen G :72-74, Schlick F :76-79) :664-679,
+// split-sum LUT fetch :681, reflection vector :693-697, specular compose :702, emissive :706,
+// sky :708-710, clamp :712-713.  IBL mode adds the commented lines :690 and :699.  The voxel-GI /
+// shadow-map / screen-space blocks are out of scope (GI == 0, shadow == 1); light shafts (:622-651)
+// are available with visibility == 1.
+//
+// Streaming kernel: 20 B read + 8 B written per pixel; irradiance / prefiltered cubes, LUT and
+// Globals are cache resident.  Discontinuous inputs (noise, sky test, N.L > 0) are evaluated in the
+// shader's operation order so that branch decisions match a CPU evaluation bit for bit.
+#include "pbr_device.h"
+#include "pbr_kernels.h"
+#include <hip/hip_fp16.h>
+
+struct ShadeParams {
+    int width, height, x0, y0, w, h;
+    const uchar4* base; const uchar4* normal; const uchar4* orm; const uchar4* emissive; const float* depth;
+    const float4* irr; int irr_size;
+    const float4* pre; int pre_size, pre_levels;
+    const __half2* lut; int lut_size;
+    void* out; int out_fmt; int flags;
+    float g[138];
+};
+
+__device__ __forceinline__ float fract_(float x) { return x - floorf(x); }
+__device__ __forceinline__ float mix_(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+// EXACT: InterleavedGradientNoise, lighting_pass.glsl:119-121
+__device__ __forceinline__ float ign(float px, float py) {
+    return fract_(52.9829189f * fract_(0.06711056f * px + 0.00583715f * py));
+}
+__device__ __forceinline__ float ggx_d(float NdotH, float roughness) {      // :21-31
+    float a = roughness * roughness;
+    float a2 = a * a;
+    float n2 = NdotH * NdotH;
+    float denom = (n2 * (a2 - 1.0f) + 1.0f);
+    denom = PBR_PI * denom * denom;
+    return a2 / denom;
+}
+__device__ __forceinline__ f3 fresnel_schlick(float c, f3 F0) {             // :76-79
+    float p = powf(1.0f - c, 5.0f);
+    return mk3(F0.x + (1.0f - F0.x) * p, F0.y + (1.0f - F0.y) * p, F0.z + (1.0f - F0.z) * p);
+}
+__device__ __forceinline__ void mat_mul(const float* m, float x, float y, float z, float w, float* o) {
+    for (int r = 0; r < 4; ++r) o[r] = ((m[r] * x + m[4 + r] * y) + m[8 + r] * z) + m[12 + r] * w;
+}
+
+__device__ __forceinline__ int bordered_level_off(int W, int level) {
+    int off = 0;
+    for (int l = 0; l < level; ++l) { int n = max(W >> l, 1) + 2; off += 6 * n * n; }
+    return off;
+}
+// trilinear fetch from a bordered pyramid (sampler: linear mip filter, LOD clamped to the chain)
+__device__ __forceinline__ f3 pyramid_fetch(const float4* __restrict__ pyr, int W, int levels, f3 d, float lod) {
+    float maxl = (float)(levels - 1);
+    lod = fminf(fmaxf(lod, 0.0f), maxl);
+    float fl = floorf(lod);
+    int l0 = (int)fl;
+    float w = lod - fl;
+    f3 c0 = cube_fetch_rgb<true>(pyr + bordered_level_off(W, l0), max(W >> l0, 1), d);
+    if (w > 0.0f) {
+        int l1 = min(l0 + 1, levels - 1);
+        f3 c1 = cube_fetch_rgb<true>(pyr + bordered_level_off(W, l1), max(W >> l1, 1), d);
+        c0.x = lerp_fma(c0.x, c1.x, w); c0.y = lerp_fma(c0.y, c1.y, w); c0.z = lerp_fma(c0.z, c1.z, w);
+    }
+    return c0;
+}
+
+__device__ __forceinline__ float2 lut_fetch(const __half2* __restrict__ lut, int S, float u, float v) {
+    float fx = u * (float)S - 0.5f, fy = v * (float)S - 0.5f;
+    float flx = floorf(fx), fly = floorf(fy);
+    float a = fx - flx, b = fy - fly;
+    int i0 = (int)flx, j0 = (int)fly;
+    int i1 = min(max(i0 + 1, 0), S - 1), j1 = min(max(j0 + 1, 0), S - 1);
+    i0 = min(max(i0, 0), S - 1); j0 = min(max(j0, 0), S - 1);
+    float2 t00 = __half22float2(lut[j0 * S + i0]), t10 = __half22float2(lut[j0 * S + i1]);
+    float2 t01 = __half22float2(lut[j1 * S + i0]), t11 = __half22float2(lut[j1 * S + i1]);
+    float2 r;
+    r.x = lerp_fma(lerp_fma(t00.x, t10.x, a), lerp_fma(t01.x, t11.x, a), b);
+    r.y = lerp_fma(lerp_fma(t00.y, t10.y, a), lerp_fma(t01.y, t11.y, a), b);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
+    int total = p.w * p.h;
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < total; id += gridDim.x * blockDim.x) {
+        int px = p.x0 + id % p.w, py = p.y0 + id / p.w;
+        size_t pi = (size_t)py * p.width + px;
+        uchar4 bb = p.base[pi], nn = p.normal[pi], oo = p.orm[pi], ee = p.emissive[pi];
+        float depth = p.depth[pi];
+
+        // :433-442
+        f3 base = mk3(bb.x / 255.0f, bb.y / 255.0f, bb.z / 255.0f);
+        f3 N = mk3(nn.x / 255.0f * 2.0f - 1.0f, nn.y / 255.0f * 2.0f - 1.0f, nn.z / 255.0f * 2.0f - 1.0f);
+        float roughness = oo.y / 255.0f, metallic = oo.z / 255.0f;
+        f3 emissive = mk3(ee.x / 255.0f * 10.0f, ee.y / 255.0f * 10.0f, ee.z / 255.0f * 10.0f);
+
+        // :444-451
+        float fs_u = ((float)px + 0.5f) / (float)p.width, fs_v = ((float)py + 0.5f) / (float)p.height;
+        float pw[4];
+        mat_mul(p.g + 32, fs_u * 2.0f - 1.0f, fs_v * 2.0f - 1.0f, depth, 1.0f, pw);   // world_space_from_clip
+        f3 P = mk3(pw[0] / pw[3], pw[1] / pw[3], pw[2] / pw[3]);
+
+        // :456-459
+        float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
+        float noise_offset = (1000 * 1.61803398875f) * p.g[135];                       // frame_idx_mod_59
+        float noise_1 = fract_(ign(fcx, fcy) + noise_offset);
+        float noise_2 = fract_(ign(fcx + 90.0f, fcy + 20.0f) + noise_offset);
+        float noise_3 = fract_(ign(fcx + 522.0f, fcy + 55.0f) + noise_offset);
+
+        const float shadow = 1.0f;                                                     // :594-608 out of scope
+        f3 cam = mk3(p.g[132], p.g[133], p.g[134]);
+        f3 V = normalize3(sub3(cam, P));                                               // :612
+        float VdotN = fmaxf(dot3(V, N), 0.0f);                                         // :613
+        f3 sun_emission = mk3(25.0f * 1.0f, 25.0f * 0.9f, 25.0f * 0.7f);               // :616
+        f3 outl = mk3(0.0f, 0.0f, 0.0f);
+
+        bool sky = (fminf(fmaxf(P.x, -99.0f), 99.0f) != P.x) | (fminf(fmaxf(P.y, -99.0f), 99.0f) != P.y) |
+                   (fminf(fmaxf(P.z, -99.0f), 99.0f) != P.z);                          // :708
+
+        if ((p.flags & PBRK_SHADE_SHAFTS) && !sky) {                                   // :622-651 (visibility == 1)
+            float sp[4], cp4[4];
+            mat_mul(p.g + 96, P.x + N.x * 0.1f, P.y + N.y * 0.1f, P.z + N.z * 0.1f, 1.0f, sp);   // :596-597 sun_space_from_world
+            mat_mul(p.g + 96, cam.x, cam.y, cam.z, 1.0f, cp4);                          // :627
+            f3 delta = mk3(sp[0] - cp4[0], sp[1] - cp4[1], sp[2] - cp4[2]);
+            float dist = sqrtf(dot3(delta, delta));
+            const float step = 1.0f / 16.0f;
+            float travelled = 0.0f;
+            travelled += step * noise_1;                                               // :638
+            // bounded: non-sky pixels lie within +-99 world units => dist < 16 in sun space
+            for (int it = 0; it < 4096; ++it) {
+                travelled += step;
+                if (travelled > dist) break;
+                outl.x += 0.001f * 1.0f * sun_emission.x;
+                outl.y += 0.001f * 1.0f * sun_emission.y;
+                outl.z += 0.001f * 1.0f * sun_emission.z;
+            }
+        }
+
+        // :657-661
+        f3 F0 = mk3(mix_(0.04f, base.x, metallic), mix_(0.04f, base.y, metallic), mix_(0.04f, base.z, metallic));
+        f3 kS = fresnel_schlick(fmaxf(dot3(N, V), 0.0f), F0);
+        f3 kD = mk3((1.0f - kS.x) * (1.0f - metallic), (1.0f - kS.y) * (1.0f - metallic), (1.0f - kS.z) * (1.0f - metallic));
+
+        // :664-679
+        {
+            f3 L = mk3(-p.g[128], -p.g[129], -p.g[130]);
+            f3 H = normalize3(add3(L, V));
+            float NdotL = fmaxf(dot3(N, L), 0.0f);
+            if (NdotL > 0.0f) {
+                float VdotH = fmaxf(dot3(V, H), 0.0f);
+                float NdotH = fmaxf(dot3(N, H), 0.0f);
+                float D = ggx_d(NdotH, roughness);
+                float G = fminf(1.0f, fminf(2.0f * NdotH * VdotN / VdotH, 2.0f * NdotH * NdotL / VdotH));
+                f3 F = fresnel_schlick(VdotH, F0);
+                float den = fmaxf(4.0f * NdotL * VdotN, 0.0001f);
+                outl.x += shadow * (kD.x * base.x / PBR_PI + F.x * G * D / den) * sun_emission.x * NdotL;
+                outl.y += shadow * (kD.y * base.y / PBR_PI + F.y * G * D / den) * sun_emission.y * NdotL;
+                outl.z += shadow * (kD.z * base.z / PBR_PI + F.z * G * D / den) * sun_emission.z * NdotL;
+            }
+        }
+
+        if (p.flags & PBRK_SHADE_IBL) {
+            float2 sb = lut_fetch(p.lut, p.lut_size, VdotN, fmaxf(roughness, 0.05f));  // :681
+            f3 irr = cube_fetch_rgb<true>(p.irr, p.irr_size, N);                              // :690
+            outl.x += kD.x * irr.x * base.x;                                           // :687
+            outl.y += kD.y * irr.y * base.y;
+            outl.z += kD.z * irr.z * base.z;
+            // :693-697
+            f3 I = mk3(-V.x, -V.y, -V.z);
+            float dNI = dot3(N, I);
+            f3 R = mk3(I.x - 2.0f * dNI * N.x, I.y - 2.0f * dNI * N.y, I.z - 2.0f * dNI * N.z);
+            float jr = 0.6f * roughness;
+            R = normalize3(mk3(R.x + jr * (noise_1 - 0.5f), R.y + jr * (noise_2 - 0.5f), R.z + jr * (noise_3 - 0.5f)));
+            float r2 = roughness * roughness;
+            float r4 = r2 * r2;
+            R = mk3(mix_(R.x, N.x, r4), mix_(R.y, N.y, r4), mix_(R.z, N.z, r4));
+            f3 spec = pyramid_fetch(p.pre, p.pre_size, p.pre_levels, R, roughness * 4.0f);   // :699
+            outl.x += spec.x * (F0.x * sb.x + sb.y);                                   // :702
+            outl.y += spec.y * (F0.y * sb.x + sb.y);
+            outl.z += spec.z * (F0.z * sb.x + sb.y);
+        }
+
+        outl = add3(outl, emissive);                                                   // :706
+        if (sky) outl = pyramid_fetch(p.pre, p.pre_size, p.pre_levels, mk3(-V.x, -V.y, -V.z), 1.0f);   // :708-710
+        outl = mk3(fmaxf(outl.x, 0.0f), fmaxf(outl.y, 0.0f), fmaxf(outl.z, 0.0f));     // :712
+
+        if (p.out_fmt == PBRK_FMT_RGBA16F) {
+            __half2 lo = __halves2half2(__float2half_rn(outl.x), __float2half_rn(outl.y));
+            __half2 hi = __halves2half2(__float2half_rn(outl.z), __float2half_rn(1.0f));
+            uint2 packed;
+            packed.x = *reinterpret_cast<unsigned*>(&lo);
+            packed.y = *reinterpret_cast<unsigned*>(&hi);
+            ((uint2*)p.out)[pi] = packed;
+        } else {
+            ((float4*)p.out)[pi] = make_float4(outl.x, outl.y, outl.z, 1.0f);
+        }
+    }
+}
+
+extern "C" int pbrk_shade(const PbrkShadeArgs* a, void* stream) {
+    if (!a || a->width < 1 || a->height < 1) return PBRK_E_ARG;
+    if (a->x0 < 0 || a->y0 < 0 || a->x1 > a->width || a->y1 > a->height || a->x0 >= a->x1 || a->y0 >= a->y1) return PBRK_E_ARG;
+    if (!a->base_color || !a->normal || !a->orm || !a->emissive || !a->depth || !a->out) return PBRK_E_ARG;
+    if (a->out_format != PBRK_FMT_RGBA16F && a->out_format != PBRK_FMT_RGBA32F) return PBRK_E_FORMAT;
+    if (!a->prefiltered_bordered || a->prefiltered_size < 1 || a->prefiltered_levels < 1 ||
+        a->prefiltered_levels > pbrk_mip_count(a->prefiltered_size, a->prefiltered_size)) return PBRK_E_ARG;   // sky branch is live code
+    if (a->flags & PBRK_SHADE_IBL) {
+        if (!a->irradiance_bordered || a->irradiance_size < 1 || !a->lut || a->lut_size < 1) return PBRK_E_ARG;
+    }
+    ShadeParams p;
+    p.width = a->width; p.height = a->height; p.x0 = a->x0; p.y0 = a->y0; p.w = a->x1 - a->x0; p.h = a->y1 - a->y0;
+    p.base = (const uchar4*)a->base_color; p.normal = (const uchar4*)a->normal; p.orm = (const uchar4*)a->orm;
+    p.emissive = (const uchar4*)a->emissive; p.depth = (const float*)a->depth;
+    p.irr = (const float4*)a->irradiance_bordered; p.irr_size = a->irradiance_size;
+    p.pre = (const float4*)a->prefiltered_bordered; p.pre_size = a->prefiltered_size; p.pre_levels = a->prefiltered_levels;
+    p.lut = (const __half2*)a->lut; p.lut_size = a->lut_size;
+    p.out = a->out; p.out_fmt = a->out_format; p.flags = a->flags;
+    for (int i = 0; i < 138; ++i) p.g[i] = a->globals[i];
+    long total = (long)p.w * p.h;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 256 * 32) grid = 256 * 32;
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+}

@@ -1,0 +1,144 @@
+// pbr_device.h -- device-side helpers shared by the gfx950 kernels.
+//
+// Compiled with -ffp-contract=off: every FMA in this code base is written explicitly (fmaf /
+// __builtin_fmaf).  Functions marked EXACT keep the operation order of the reference shader text
+// (separately rounded IEEE fp32 ops, correctly rounded / and sqrt) so that quantities feeding
+// discontinuous or ill-conditioned expressions (texel directions, tangent frames, noise, N.H near 1)
+// come out bit-identical to a scalar CPU evaluation; the hot inner loops use explicit FMAs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PBR_PI 3.14159265358979323846f
+
+struct f3 { float x, y, z; };
+
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+// EXACT: GLSL dot / cross / normalize in source order
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b) {
+    return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+__device__ __forceinline__ f3 normalize3(f3 a) {
+    float len = sqrtf(dot3(a, a));   // correctly rounded expansion (unlike __fsqrt_rn, which is the 1-ulp v_sqrt_f32)
+    return mk3(__fdiv_rn(a.x, len), __fdiv_rn(a.y, len), __fdiv_rn(a.z, len));
+}
+
+// EXACT: CubemapSampleDirFromFaceUV (reference shaders/gen_prefiltered_env_map.glsl:11-66):
+// texel (ix,iy) of an n*n face -> unit direction through the texel centre.
+__device__ __forceinline__ f3 face_texel_dir(int face, int ix, int iy, int n) {
+    float u = __fdiv_rn((float)ix + 0.5f, (float)n);
+    float v = __fdiv_rn((float)iy + 0.5f, (float)n);
+    float sc = 2 * (u - 0.5f);
+    float tc = 2 * (v - 0.5f);
+    f3 r;
+    switch (face) {
+    case 0: r = mk3(1.0f, -tc, -sc); break;
+    case 1: r = mk3(-1.0f, -tc, sc); break;
+    case 2: r = mk3(sc, 1.0f, tc); break;
+    case 3: r = mk3(sc, -1.0f, -tc); break;
+    case 4: r = mk3(sc, -tc, 1.0f); break;
+    default: r = mk3(-sc, -tc, -1.0f); break;
+    }
+    return normalize3(r);
+}
+
+// EXACT: tangent = normalize(cross(R, some_vector)) (gen_prefiltered_env_map.glsl:108-109)
+__device__ __forceinline__ f3 tangent_of(f3 R) {
+    return normalize3(cross3(R, mk3(12.123825810901f, 6.11831989512f, -5.12039214121f)));
+}
+
+// ---- cube addressing on the BORDERED layout -----------------------------------------------
+// A bordered level stores each face as (n+2)*(n+2) float4 texels: the interior is the face, the
+// one-texel apron holds the adjacent faces' edge texels (corners: mean of the three existing
+// texels).  Seamless bilinear filtering then needs no branches: taps are (i0,j0)..(i0+1,j0+1)
+// with i0 = floor(s*n - 0.5) + 1 in [0, n].
+//
+// Face selection follows the Vulkan table quoted in gen_prefiltered_env_map.glsl:12-23
+// (major axis = largest magnitude, ties z > y > x).
+struct CubeTap {
+    int base;      // texel index of tap (i0, j0) inside the bordered level (face included)
+    float a, b;    // bilinear weights along x and y
+};
+
+// EXACT = false: one v_rcp_f32 + FMAs (Monte-Carlo inner loops: coordinate rounding noise averages out over
+//                thousands of samples).
+// EXACT = true : the projection in separately rounded IEEE ops, s = (0.5*sc)/|rc| + 0.5, u = s*n - 0.5
+//                (single-sample lookups: K4a copy, shade pass) so that tap selection and weights are
+//                bit-identical to a scalar CPU evaluation even next to a 5e4:1 HDR sun texel.
+template <bool EXACT>
+__device__ __forceinline__ CubeTap cube_tap(f3 d, int n) {
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int face; float sc, tc, ma;
+    if (az >= ax && az >= ay) {
+        bool neg = d.z < 0.0f; face = neg ? 5 : 4; sc = neg ? -d.x : d.x; tc = -d.y; ma = az;
+    } else if (ay >= ax) {
+        bool neg = d.y < 0.0f; face = neg ? 3 : 2; sc = d.x; tc = neg ? -d.z : d.z; ma = ay;
+    } else {
+        bool neg = d.x < 0.0f; face = neg ? 1 : 0; sc = neg ? d.z : -d.z; tc = -d.y; ma = ax;
+    }
+    float u, v;
+    if (EXACT) {
+        float s = 0.5f * sc / ma + 0.5f;
+        float t = 0.5f * tc / ma + 0.5f;
+        u = s * (float)n - 0.5f;                          // unbordered coordinate, as the sampler definition states it
+        v = t * (float)n - 0.5f;
+    } else {
+        float h = 0.5f * __builtin_amdgcn_rcpf(ma) * (float)n;   // (0.5 / |rc|) * n
+        float off = 0.5f * (float)n + 0.5f;                      // s*n - 0.5 + 1 = sc*h + n/2 + 0.5 (bordered)
+        u = fmaf(sc, h, off);
+        v = fmaf(tc, h, off);
+    }
+    float fu = floorf(u), fv = floorf(v);
+    int i0 = (int)fu + (EXACT ? 1 : 0), j0 = (int)fv + (EXACT ? 1 : 0);
+    // keep taps inside the apron whatever the input (NaN directions included)
+    i0 = min(max(i0, 0), n);
+    j0 = min(max(j0, 0), n);
+    CubeTap t;
+    t.a = u - fu; t.b = v - fv;
+    int nb = n + 2;
+    t.base = (face * nb + j0) * nb + i0;
+    return t;
+}
+
+__device__ __forceinline__ float lerp_fma(float p, float q, float t) { return fmaf(t, q - p, p); }
+
+// bilinear RGB fetch from a bordered level (global memory or LDS pointer)
+template <bool EXACT>
+__device__ __forceinline__ f3 cube_fetch_rgb(const float4* __restrict__ lvl, int n, f3 d) {
+    CubeTap t = cube_tap<EXACT>(d, n);
+    int nb = n + 2;
+    float4 t00 = lvl[t.base], t10 = lvl[t.base + 1];
+    float4 t01 = lvl[t.base + nb], t11 = lvl[t.base + nb + 1];
+    f3 r;
+    r.x = lerp_fma(lerp_fma(t00.x, t10.x, t.a), lerp_fma(t01.x, t11.x, t.a), t.b);
+    r.y = lerp_fma(lerp_fma(t00.y, t10.y, t.a), lerp_fma(t01.y, t11.y, t.a), t.b);
+    r.z = lerp_fma(lerp_fma(t00.z, t10.z, t.a), lerp_fma(t01.z, t11.z, t.a), t.b);
+    return r;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ float4 cube_fetch_rgba(const float4* __restrict__ lvl, int n, f3 d) {
+    CubeTap t = cube_tap<EXACT>(d, n);
+    int nb = n + 2;
+    float4 t00 = lvl[t.base], t10 = lvl[t.base + 1];
+    float4 t01 = lvl[t.base + nb], t11 = lvl[t.base + nb + 1];
+    float4 r;
+    r.x = lerp_fma(lerp_fma(t00.x, t10.x, t.a), lerp_fma(t01.x, t11.x, t.a), t.b);
+    r.y = lerp_fma(lerp_fma(t00.y, t10.y, t.a), lerp_fma(t01.y, t11.y, t.a), t.b);
+    r.z = lerp_fma(lerp_fma(t00.z, t10.z, t.a), lerp_fma(t01.z, t11.z, t.a), t.b);
+    r.w = lerp_fma(lerp_fma(t00.w, t10.w, t.a), lerp_fma(t01.w, t11.w, t.a), t.b);
+    return r;
+}
+
+// XCD-aware remap of a 1-D block index (workgroups b and b+8 share an XCD/L2): consecutive
+// logical tiles are placed on the same XCD so that tiles that share source texels share an L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
+    unsigned q = nblocks >> 3, r = nblocks & 7u;
+    unsigned xcd = bid & 7u, idx = bid >> 3;
+    unsigned start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
