@@ -1,0 +1,365 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the IBL-precompute hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c2|ref]
+  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full IBL precompute of the workload with the environment cube's level 0 already
+resident in HBM: mip-chain build (K2) + apron build + specular prefilter of every mip (K4a copy,
+K4b Monte-Carlo) + diffuse irradiance (K3), driven through the GPU_* C ABI exactly as the reference's
+HotreloadShaders does (render.cpp:505-589).  With N ranks the (mip, face, row-tile) work units are
+cost-partitioned over the ranks (strong scaling: the job is fixed) and the output tiles are gathered
+to rank 0 with one grouped RCCL send/recv batch per step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+HIP-event timed on the stream it runs on) and `cpu_baseline` (the scalar C oracle timed on the host).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "vulkan-pbr-renderer_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+WORKLOADS = {
+    # name: (env W, specular size, irradiance size, seed, description)
+    "c4": (2048, 4096, 128, 0x5EED0004, "C4: 4096x4096 specular prefilter (6 faces, 13 mips) + 128x128 irradiance from a 2048^2 HDR cube"),
+    "c2": (1024, 512, 32, 0x5EED0001, "C2: 512x512 specular prefilter (6 faces, 10 mips) + 32x32 irradiance from a 1024^2 HDR cube"),
+    "ref": (256, 256, 32, 0x5EED00AB, "reference sizes: 256x256 specular (mips 0-4) + 32x32 irradiance from a 256^2 HDR cube"),
+}
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PEAK_FP32_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
+FLOP_PER_SAMPLE = 65.0         # frame transform + face select + projection + 4-tap RGB lerp + accumulate
+
+
+def load_env(W, seed, workers):
+    from pbrhip import synth
+    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pbr_env_{W}_{seed:08x}.npy")
+    if os.path.exists(cache):
+        try:
+            a = np.load(cache)
+            if a.shape == (6, W, W, 4):
+                return a
+        except Exception:
+            pass
+    a = synth.synth_env(W, seed=seed, workers=workers)
+    try:
+        tmp = cache + f".{os.getpid()}.tmp.npy"
+        np.save(tmp, a)
+        os.replace(tmp, cache)
+    except Exception:
+        pass
+    return a
+
+
+def nonzero_weight_count(L, nsamples, roughness):
+    tab = np.zeros((nsamples, 4), np.float32)
+    alpha = C.c_float()
+    return L.pbrk_host_prefilter_table(nsamples, C.c_float(roughness), tab.ctypes.data_as(C.c_void_p), C.byref(alpha))
+
+
+def ref_roughness(mip):
+    if mip < 5:
+        return [0.0, 0.03, 0.15, 0.4, 0.6][mip]
+    return min(1.0, float(np.float32(0.6) + np.float32(0.08) * np.float32(mip - 4)))
+
+
+def cpu_baseline(env, W, spec_size, irr_size, budget_s=15.0):
+    """Scalar C oracle (oracle/pbr_oracle.c, 'port') timed on the host cores over a bounded sample of the same job."""
+    import pbr_oracle as O
+    threads = O.get_threads()
+    pyr = O.build_pyramid(env)
+    nm = O.mip_count(spec_size)
+    t_mc = 0.0; n_mc = 0
+    t_cp = 0.0; n_cp = 0
+    # copy mip: a few rows of every face
+    size0 = spec_size
+    rows = max(1, min(size0, 16))
+    t = time.perf_counter()
+    O.prefilter_mip(pyr, W, spec_size, 0, rows=(0, rows))
+    t_cp += time.perf_counter() - t; n_cp += 6 * rows * size0
+    # Monte-Carlo mips: row slices of increasing size until the budget is spent
+    deadline = time.perf_counter() + budget_s
+    sample_desc = []
+    for mip in (2, 1, 3, 4):
+        if mip >= nm:
+            continue
+        size = max(1, spec_size >> mip)
+        r = max(1, min(size, (threads * 2 + 5) // 6))
+        while time.perf_counter() < deadline:
+            t = time.perf_counter()
+            O.prefilter_mip(pyr, W, spec_size, mip, rows=(0, r))
+            dt = time.perf_counter() - t
+            t_mc += dt; n_mc += 6 * r * size
+            sample_desc.append(f"mip{mip}:{6 * r * size}tx")
+            if dt > budget_s / 8 or r >= size:
+                break
+            r = min(size, r * 2)
+    rate_mc = n_mc / t_mc if t_mc > 0 else float("nan")       # MC texels / s (8192 samples each, no zero-weight skipping)
+    rate_cp = n_cp / t_cp
+    total_mc = sum(6 * max(1, spec_size >> m) ** 2 for m in range(1, nm)) + 6 * irr_size * irr_size / 8.0
+    total_cp = 6 * spec_size * spec_size
+    est_time = total_mc / rate_mc + total_cp / rate_cp
+    total_units = total_cp + sum(6 * max(1, spec_size >> m) ** 2 for m in range(1, nm)) + 6 * irr_size * irr_size
+    return {
+        "value": total_units / est_time / 1e6, "unit": "Mtexels/s", "cores": threads, "kind": "port",
+        "sample": f"oracle/pbr_oracle.c (OpenMP, {threads} threads): {n_cp} copy texels + {n_mc} Monte-Carlo texels x 8192 samples "
+                  f"({', '.join(sample_desc[:6])}) in {t_mc + t_cp:.1f} s, extrapolated to the whole job "
+                  f"({rate_mc * 8192 / 1e6:.1f} Msamples/s, est. {est_time:.0f} s per job)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shade", action="store_true")
+    ap.add_argument("--check", action="store_true", help="after the run, spot-check output texels against the oracle")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+
+    W, spec_size, irr_size, seed, desc = WORKLOADS[args.workload]
+    # inputs first (fork-based workers), GPU afterwards
+    env = load_env(W, seed, workers=max(1, min(6, (os.cpu_count() or 8) // max(1, world))))
+
+    import torch
+    import torch.distributed as dist
+    import pbrhip
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    L = pbrhip.init(device=local_rank)
+    L.GPUX_EnableOpTiming(1)
+
+    # ---- resources: env cube (level 0 resident), output maps over torch-owned HBM (so RCCL can move them)
+    env_tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, W, W, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+    spec_flags = pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps | pbrhip.TextureFlag_StorageImage
+    n_mips = L.pbrk_mip_count(spec_size, spec_size)
+    spec_floats = L.pbrk_pyramid_texels(spec_size, n_mips) * 4
+    spec_mem = torch.zeros(spec_floats, dtype=torch.float32, device="cuda")
+    irr_mem = torch.zeros(6 * irr_size * irr_size * 4, dtype=torch.float32, device="cuda")
+    maps = pbrhip.PBR_IBLMaps()
+    maps.tex_specular_env_map = L.GPUX_MakeTextureExternal(pbrhip.Format_RGBA32F, spec_size, spec_size, 1, spec_flags,
+                                                           spec_mem.data_ptr(), spec_mem.numel() * 4)
+    maps.irradiance_map = L.GPUX_MakeTextureExternal(pbrhip.Format_RGBA32F, irr_size, irr_size, 1,
+                                                     pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_StorageImage,
+                                                     irr_mem.data_ptr(), irr_mem.numel() * 4)
+    maps.brdf_lut = pbrhip.make_texture(pbrhip.Format_RG16F, 256, 256, pbrhip.TextureFlag_StorageImage)
+    L.PBR_GenBRDFIntegrationMap(maps.brdf_lut)          # 256 KB: computed redundantly on every rank, not timed
+
+    my_units, n_my = pbrhip.partition(spec_size, 1, irr_size, W, world, rank)
+    all_units = []
+    if world > 1:
+        for r in range(world):
+            u, n = pbrhip.partition(spec_size, 1, irr_size, W, world, r)
+            all_units.append([(u[i].kind, u[i].mip, u[i].face0, u[i].face1, u[i].row0, u[i].row1) for i in range(n)])
+
+    def unit_slice(kind, mip, f0, f1, r0, r1):
+        """Flat float range of one work unit inside spec_mem / irr_mem (faces are consecutive: one unit = one face)."""
+        if kind == pbrhip.Unit_Irradiance:
+            size, base, mem = irr_size, 0, irr_mem
+        else:
+            size, base, mem = max(1, spec_size >> mip), L.pbrk_level_offset(spec_size, mip) * 4, spec_mem
+        assert f1 == f0 + 1 or (r0 == 0 and r1 == size)
+        a = base + ((f0 * size + r0) * size) * 4
+        b = base + (((f1 - 1) * size + r1) * size) * 4
+        return mem[a:b]
+
+    pipes = L.PBR_MakeIBLPipelines()
+    arena = L.GPU_MakeDescriptorArena()
+    graph = L.GPU_MakeGraph()
+
+    def step():
+        L.GPU_OpGenerateMipmaps(graph, env_tex)                                   # K2 (+ apron rebuild on first sample)
+        L.PBR_RecordUnits(pipes, graph, arena, env_tex, C.byref(maps), my_units, n_my)
+        L.GPU_GraphSubmit(graph)
+        L.GPU_GraphWait(graph)
+        L.GPU_ResetDescriptorArena(arena)
+        if world > 1:                                                             # one grouped RCCL exchange: tiles -> rank 0
+            ops = []
+            if rank == 0:
+                for r in range(1, world):
+                    for u in all_units[r]:
+                        ops.append(dist.P2POp(dist.irecv, unit_slice(*u), r))
+            else:
+                for u in all_units[rank]:
+                    ops.append(dist.P2POp(dist.isend, unit_slice(*u), 0))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        L.GPU_WaitUntilIdle()
+
+    for _ in range(args.warmup):
+        step()
+    op_ms = {}
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for i in range(L.GPUX_GraphTimedOpCount(graph)):
+            nm = L.GPUX_GraphTimedOpName(graph, i).decode()
+            op_ms.setdefault(nm, []).append(L.GPUX_GraphTimedOpMs(graph, i))
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    total_texels = sum(6 * max(1, spec_size >> m) ** 2 for m in range(n_mips)) + 6 * irr_size * irr_size
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_texels * args.steps / elapsed / 1e6
+
+    # ---- per-kernel accounting (this rank's launches; at N=1 one launch per output level)
+    kernels = []
+    for nm, v in op_ms.items():
+        ms = float(np.mean(v))
+        launches_per_step = len(v) / args.steps
+        ent = {"kernel": nm, "avg_ms": ms, "launches_per_step": launches_per_step}
+        if world == 1 and nm.startswith("K4b.prefilter_mc.mip"):
+            mip = int(nm.rsplit("mip", 1)[1])
+            size = max(1, spec_size >> mip)
+            nz = nonzero_weight_count(L, 8192, ref_roughness(mip))
+            samples = 6.0 * size * size * nz
+            ent.update(bound="valu", samples=samples, flop=samples * FLOP_PER_SAMPLE,
+                       achieved_tflops=samples * FLOP_PER_SAMPLE / (ms * 1e-3) / 1e12,
+                       alg_bytes=6.0 * size * size * 16, msamples_per_s=samples / (ms * 1e-3) / 1e6)
+            ent["frac"] = ent["achieved_tflops"] / PEAK_FP32_TFLOPS
+        elif world == 1 and nm == "K3.irradiance":
+            samples = 6.0 * irr_size * irr_size * 1024
+            ent.update(bound="valu", samples=samples, flop=samples * FLOP_PER_SAMPLE,
+                       achieved_tflops=samples * FLOP_PER_SAMPLE / (ms * 1e-3) / 1e12)
+            ent["frac"] = ent["achieved_tflops"] / PEAK_FP32_TFLOPS
+        elif world == 1 and nm.startswith("K4a."):
+            src = 6.0 * (W // 2) ** 2 * 16
+            byt = 6.0 * spec_size * spec_size * 16 + src
+            ent.update(bound="hbm", alg_bytes=byt, achieved_gbs=byt / (ms * 1e-3) / 1e9)
+            ent["frac"] = ent["achieved_gbs"] / PEAK_HBM_GBS
+        elif world == 1 and nm == "K2.mip_chain":
+            byt = 80.0 * 6 * W * W / 3.0
+            ent.update(bound="hbm", alg_bytes=byt, achieved_gbs=byt / (ms * 1e-3) / 1e9)
+            ent["frac"] = ent["achieved_gbs"] / PEAK_HBM_GBS
+        kernels.append(ent)
+    kernels.sort(key=lambda e: -e["avg_ms"] * e["launches_per_step"])
+
+    roofline = None
+    if world == 1 and kernels:
+        dom = next((k for k in kernels if "frac" in k), None)
+        if dom is not None:
+            if dom["bound"] == "valu":
+                roofline = {"kernel": dom["kernel"], "bound": "valu", "achieved": dom["achieved_tflops"], "peak": PEAK_FP32_TFLOPS,
+                            "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None,
+                            "note": "Monte-Carlo mips are fp32-VALU bound (SURVEY S9): 65 algorithmic flop per non-zero-weight sample; "
+                                    "the HBM-shaped kernels are listed under roofline_hbm"}
+            else:
+                roofline = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["achieved_gbs"], "peak": PEAK_HBM_GBS,
+                            "unit": "GB/s", "frac": dom["frac"], "traffic": None}
+    roofline_hbm = [{"kernel": k["kernel"], "bound": "hbm", "achieved": k["achieved_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": k["frac"], "avg_ms": k["avg_ms"]} for k in kernels if k.get("bound") == "hbm"]
+
+    extra = {}
+    if rank == 0 and not args.no_shade:
+        try:
+            extra["shade"] = shade_bench(L, pbrhip, maps, world)
+        except Exception as e:      # the headline number must not depend on the extra
+            extra["shade_error"] = repr(e)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(env, W, spec_size, irr_size)
+
+    if args.check and rank == 0:
+        import pbr_oracle as O
+        pyr = O.build_pyramid(env)
+        worst = 0.0
+        for mip in range(min(n_mips, 6)):
+            size = max(1, spec_size >> mip)
+            off = L.pbrk_level_offset(spec_size, mip) * 4
+            got = spec_mem[off: off + 6 * size * size * 4].cpu().numpy().reshape(6, size, size, 4)
+            for (f, y) in ((0, 0), (3, size // 2), (5, size - 1)):
+                want = O.prefilter_mip(pyr, W, spec_size, mip, faces=(f, f + 1), rows=(y, y + 1))[f, y]
+                err = np.abs(got[f, y].astype(np.float64) - want) / np.maximum(np.abs(want), 1e-3)
+                worst = max(worst, float(err.max()))
+        extra["check_max_rel_err_vs_oracle"] = worst
+
+    if rank == 0:
+        out = {
+            "metric": "IBL-prefilter Mtexels/s (specular prefilter all mips + irradiance; PBR-shaded Mpixels/s under extra.shade)",
+            "value": value, "unit": "Mtexels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "env": f"procedural HDR cube {W}^2 x6 RGBA32F (seed {seed:#x}, RGBE round-tripped)",
+                       "texels_per_step": total_texels,
+                       "parallelism": "single GPU" if world == 1 else f"{world} ranks, cost-partitioned (mip,face,row-tile) units, 1 grouped RCCL send/recv gather per step"},
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "kernels": kernels[:12],
+            "cpu_baseline": cpu, "extra": extra,
+        }
+        print(json.dumps(out))
+
+    L.GPU_DestroyGraph(graph)
+    L.GPU_DestroyDescriptorArena(arena)
+    L.PBR_DestroyIBLPipelines(pipes)
+    L.GPU_DestroyTexture(maps.tex_specular_env_map); L.GPU_DestroyTexture(maps.irradiance_map); L.GPU_DestroyTexture(maps.brdf_lut)
+    L.GPU_DestroyTexture(env_tex)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def shade_bench(L, pbrhip, maps, world, frames=20):
+    """C3: 1920x1080 synthetic metal-rough-spheres G-buffer through the lighting pass (K5), IBL maps from this run."""
+    from pbrhip import synth
+    W, H = 1920, 1080
+    gbd = synth.synth_gbuffer_spheres(W, H)
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), W, H, pbrhip.Format_RGBA16F)
+    for name, arr in (("base_color", gbd["base"]), ("normal", gbd["normal"]), ("orm", gbd["orm"]),
+                      ("emissive", gbd["emissive"]), ("depth", gbd["depth"])):
+        pbrhip.upload_mip(getattr(gb, name), 0, arr)
+    lp = L.PBR_MakeLightingPass(C.byref(gb), C.byref(maps), W, H)
+    glob = pbrhip.fill_globals(gbd["cam_pos"], aspect=W / H)
+    g = L.GPU_MakeGraph()
+    L.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)                      # warm-up (builds the aprons)
+    for _ in range(frames):
+        L.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
+    t0 = time.perf_counter()
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    wall = time.perf_counter() - t0
+    ms = [L.GPUX_GraphTimedOpMs(g, i) for i in range(L.GPUX_GraphTimedOpCount(g))
+          if L.GPUX_GraphTimedOpName(g, i).decode() == "K5.shade"]
+    k_ms = float(np.mean(ms)) if ms else float("nan")
+    byt = 28.0 * W * H
+    res = {"workload": "C3: 1920x1080 G-buffer Cook-Torrance shade pass (IBL mode), RGBA16F target", "frames": frames,
+           "kernel_avg_ms": k_ms, "mpixels_per_s_kernel": W * H / (k_ms * 1e-3) / 1e6,
+           "mpixels_per_s_wall": W * H * frames / wall / 1e6,
+           "roofline": {"kernel": "K5.shade", "bound": "hbm", "achieved": byt / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": byt / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}}
+    L.GPU_DestroyGraph(g); L.PBR_DestroyLightingPass(lp); L.PBR_DestroyGBuffer(C.byref(gb))
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -48,6 +48,13 @@ GPU_API void* GPUX_TextureDevicePtr(GPU_Texture* texture, uint32_t mip_level);  
 GPU_API void* GPUX_BufferDevicePtr(GPU_Buffer* buffer);
 GPU_API void* GPUX_GraphStream(GPU_Graph* graph);                                         /* hipStream_t */
 
+/* ---- textures over caller-owned HBM (e.g. a torch tensor that RCCL gathers into): same layout as GPU_MakeTexture,
+ * [mip][layer][y][x] tight; the caller keeps the allocation alive and frees it after GPU_DestroyTexture. ---- */
+GPU_API GPU_Texture* GPUX_MakeTextureExternal(GPU_Format format, uint32_t width, uint32_t height, uint32_t depth, GPU_TextureFlags flags,
+                                              void* device_memory, uint64_t device_bytes);
+GPU_API uint64_t GPUX_TextureTotalBytes(const GPU_Texture* texture);
+GPU_API uint64_t GPUX_TextureMipOffset(const GPU_Texture* texture, uint32_t mip_level);
+
 /* ---- per-op timing with HIP events on the graph's own stream ---- */
 GPU_API void GPUX_EnableOpTiming(int enable);
 GPU_API uint32_t GPUX_GraphTimedOpCount(GPU_Graph* graph);          /* ops of the last waited submission */

@@ -64,6 +64,7 @@ struct TextureImpl {
     void* bordered = nullptr;         // bordered pyramid twin (RGBA32F cubes only), built on demand
     size_t bordered_bytes = 0;
     bool bordered_valid = false;
+    bool owns_memory = true;          // false: GPUX_MakeTextureExternal (caller-owned HBM, e.g. a torch tensor)
 };
 struct BufferImpl {
     GPU_Buffer base;
@@ -350,11 +351,12 @@ static bool is_f4_cube(const TextureImpl* t) {
     return t->base.format == GPU_Format_RGBA32F && (t->base.flags & GPU_TextureFlag_Cubemap) && t->base.width == t->base.height && t->base.depth == 1;
 }
 
-GPU_API GPU_Texture* GPU_MakeTexture(GPU_Format format, uint32_t width, uint32_t height, uint32_t depth, GPU_TextureFlags flags, const void* data) {
-    GPU_REQUIRE(G.init, nullptr, "GPU_MakeTexture: GPU_Init has not been called");
-    GPU_REQUIRE(width > 0 && height > 0 && depth > 0, nullptr, "GPU_MakeTexture: zero extent");   // gpu_vulkan.c:1339
+static GPU_Texture* make_texture_impl(GPU_Format format, uint32_t width, uint32_t height, uint32_t depth, GPU_TextureFlags flags,
+                                      const void* data, void* external, uint64_t external_bytes, const char* fn) {
+    GPU_REQUIRE(G.init, nullptr, "%s: GPU_Init has not been called", fn);
+    GPU_REQUIRE(width > 0 && height > 0 && depth > 0, nullptr, "%s: zero extent", fn);   // gpu_vulkan.c:1339
     GPU_FormatInfo fi = GPUX_GetFormatInfo(format);
-    GPU_REQUIRE(fi.block_size > 0, nullptr, "GPU_MakeTexture: invalid format %d", (int)format);
+    GPU_REQUIRE(fi.block_size > 0, nullptr, "%s: invalid format %d", fn, (int)format);
     TextureImpl* t = new TextureImpl();
     t->base.width = width; t->base.height = height; t->base.depth = depth;
     t->base.layer_count = (flags & GPU_TextureFlag_Cubemap) ? 6 : 1;
@@ -369,17 +371,22 @@ GPU_API GPU_Texture* GPU_MakeTexture(GPU_Format format, uint32_t width, uint32_t
     size_t off = 0;
     for (uint32_t m = 0; m < mips; ++m) { t->mip_offset.push_back(off); off += (size_t)GPUX_TextureMipBytes(&t->base, m); }
     t->bytes = off;
-    hipError_t e = hipMalloc(&t->dev, t->bytes);
-    if (e != hipSuccess) { gpu_fail("GPU_MakeTexture: hipMalloc(%zu) failed: %s", t->bytes, hipGetErrorString(e)); delete t; return nullptr; }
-    HIP_OK(hipMemset(t->dev, 0, t->bytes));
+    if (external) {
+        if (external_bytes < t->bytes) { gpu_fail("%s: external allocation of %llu bytes is smaller than the %zu the texture needs", fn, (unsigned long long)external_bytes, t->bytes); delete t; return nullptr; }
+        t->dev = external; t->owns_memory = false;
+    } else {
+        hipError_t e = hipMalloc(&t->dev, t->bytes);
+        if (e != hipSuccess) { gpu_fail("%s: hipMalloc(%zu) failed: %s", fn, t->bytes, hipGetErrorString(e)); delete t; return nullptr; }
+        HIP_OK(hipMemset(t->dev, 0, t->bytes));
+    }
     if (data) {
         HIP_OK(hipMemcpy(t->dev, data, (size_t)GPUX_TextureMipBytes(&t->base, 0), hipMemcpyHostToDevice));
         if (mips > 1) {                                                        // gpu_vulkan.c:1444-1446
             if (!is_f4_cube(t) || (width & (width - 1))) {
-                gpu_fail("GPU_MakeTexture: mip generation is implemented for power-of-two RGBA32F cubemaps only");
+                gpu_fail("%s: mip generation is implemented for power-of-two RGBA32F cubemaps only", fn);
             } else {
                 int rc = pbrk_mip_chain(t->dev, (int)width, (int)mips, nullptr);
-                if (rc != PBRK_OK) gpu_fail("GPU_MakeTexture: mip chain kernel failed (%d)", rc);
+                if (rc != PBRK_OK) gpu_fail("%s: mip chain kernel failed (%d)", fn, rc);
                 HIP_OK(hipStreamSynchronize(nullptr));                          // :1448-1449 blocking
             }
         }
@@ -387,11 +394,24 @@ GPU_API GPU_Texture* GPU_MakeTexture(GPU_Format format, uint32_t width, uint32_t
     return &t->base;
 }
 
+GPU_API GPU_Texture* GPU_MakeTexture(GPU_Format format, uint32_t width, uint32_t height, uint32_t depth, GPU_TextureFlags flags, const void* data) {
+    return make_texture_impl(format, width, height, depth, flags, data, nullptr, 0, __func__);
+}
+GPU_API GPU_Texture* GPUX_MakeTextureExternal(GPU_Format format, uint32_t width, uint32_t height, uint32_t depth, GPU_TextureFlags flags,
+                                              void* device_memory, uint64_t device_bytes) {
+    GPU_REQUIRE(device_memory, nullptr, "GPUX_MakeTextureExternal: NULL device memory");
+    return make_texture_impl(format, width, height, depth, flags, nullptr, device_memory, device_bytes, __func__);
+}
+GPU_API uint64_t GPUX_TextureTotalBytes(const GPU_Texture* t) { return t ? ((const TextureImpl*)t)->bytes : 0; }
+GPU_API uint64_t GPUX_TextureMipOffset(const GPU_Texture* t, uint32_t mip) {
+    return (t && mip < t->mip_level_count) ? ((const TextureImpl*)t)->mip_offset[mip] : 0;
+}
+
 GPU_API void GPU_DestroyTexture(GPU_Texture* tex) {
     if (!tex) return;
     TextureImpl* t = (TextureImpl*)tex;
-    hipFree(t->dev);
-    if (t->bordered) hipFree(t->bordered);
+    if (t->owns_memory) (void)hipFree(t->dev);
+    if (t->bordered) (void)hipFree(t->bordered);
     delete t;
 }
 

@@ -211,6 +211,23 @@ uint32_t PBR_PartitionIBL(uint32_t specular_size, uint32_t min_size, uint32_t ir
     }
     if (irradiance_size) total += 6.0 * irradiance_size * irradiance_size * 1024.0;
     double target = total / (8.0 * world);
+    if (world == 1 && rank <= 0) {
+        /* single GPU: one dispatch per output level (the reference's own granularity, render.cpp:564-580) */
+        uint32_t n1 = 0;
+        for (uint32_t m = 0; m <= mips; ++m) {
+            int irr = m == mips;
+            if (irr && !irradiance_size) break;
+            uint32_t size = irr ? irradiance_size : (specular_size >> m ? specular_size >> m : 1);
+            if (out && n1 < capacity) {
+                PBR_WorkUnit* u = &out[n1];
+                u->kind = irr ? PBR_Unit_Irradiance : PBR_Unit_Prefilter;
+                u->mip = irr ? 0 : m; u->face0 = 0; u->face1 = 6; u->row0 = 0; u->row1 = size;
+                u->cost = 6.0 * size * size * (irr ? 1024.0 : samples_per_texel(m));
+            }
+            ++n1;
+        }
+        return n1;
+    }
     uint32_t cap_all = 0, n = 0;
     PBR_WorkUnit* all = NULL;
     for (int pass = 0; pass < 2; ++pass) {

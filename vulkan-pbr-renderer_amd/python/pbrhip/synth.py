@@ -127,40 +127,52 @@ SUN_DIR = np.array([0.35, 0.55, 0.757], dtype=np.float64)
 SUN_DIR /= np.linalg.norm(SUN_DIR)
 
 
-def synth_env(W, seed=0x5EED0001, rgbe_roundtrip=True, chunk_rows=256):
-    """Procedural HDR cube [6][W][W][4] float32: sky gradient + sun disc (peak 5e4) + horizon band
-    + value noise, round-tripped through RGBE so the values are what stbi_loadf would return."""
-    out = np.empty((6, W, W, 4), dtype=np.float32)
+def _env_face(args):
+    W, seed, rgbe_roundtrip, f, chunk_rows = args
+    out = np.empty((W, W, 4), dtype=np.float32)
     c = (np.arange(W, dtype=np.float64) + 0.5) / W
-    for f in range(6):
-        for y0 in range(0, W, chunk_rows):
-            y1 = min(W, y0 + chunk_rows)
-            u, v = np.meshgrid(c, c[y0:y1], indexing="xy")
-            sc, tc = 2 * (u - 0.5), 2 * (v - 0.5)
-            one = np.ones_like(sc)
-            comps = [(one, -tc, -sc), (-one, -tc, sc), (sc, one, tc), (sc, -one, -tc), (sc, -tc, one), (-sc, -tc, -one)][f]
-            d = np.stack(comps, axis=-1)
-            d /= np.linalg.norm(d, axis=-1, keepdims=True)
-            up = d[..., 2]
-            t = np.clip(up * 0.5 + 0.5, 0, 1)
-            sky = np.stack([0.25 + 0.5 * t, 0.35 + 0.65 * t, 0.55 + 0.95 * t], axis=-1)
-            ground = np.stack([0.18 + 0 * t, 0.15 + 0 * t, 0.12 + 0 * t], axis=-1)
-            col = np.where((up > 0)[..., None], sky, ground)
-            band = np.exp(-(up / 0.06) ** 2)
-            col = col + band[..., None] * np.array([0.9, 0.7, 0.45])
-            n1 = value_noise3(d * 6.0 + 17.0, seed)
-            n2 = value_noise3(d * 23.0 + 5.0, seed ^ 0x9E3779B9)
-            col = col * (0.6 + 0.5 * n1 + 0.3 * n2)[..., None]
-            cs = d @ SUN_DIR
-            ang = np.arccos(np.clip(cs, -1, 1))
-            sun = 5.0e4 * np.exp(-(ang / 0.012) ** 4) + 40.0 * np.exp(-(ang / 0.08) ** 2)
-            col = col + sun[..., None] * np.array([1.0, 0.92, 0.8])
-            if rgbe_roundtrip:
-                out[f, y0:y1] = rgbe_decode(rgbe_encode(col))
-            else:
-                out[f, y0:y1, :, :3] = col.astype(np.float32)
-                out[f, y0:y1, :, 3] = 1.0
+    for y0 in range(0, W, chunk_rows):
+        y1 = min(W, y0 + chunk_rows)
+        u, v = np.meshgrid(c, c[y0:y1], indexing="xy")
+        sc, tc = 2 * (u - 0.5), 2 * (v - 0.5)
+        one = np.ones_like(sc)
+        comps = [(one, -tc, -sc), (-one, -tc, sc), (sc, one, tc), (sc, -one, -tc), (sc, -tc, one), (-sc, -tc, -one)][f]
+        d = np.stack(comps, axis=-1)
+        d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        up = d[..., 2]
+        t = np.clip(up * 0.5 + 0.5, 0, 1)
+        sky = np.stack([0.25 + 0.5 * t, 0.35 + 0.65 * t, 0.55 + 0.95 * t], axis=-1)
+        ground = np.stack([0.18 + 0 * t, 0.15 + 0 * t, 0.12 + 0 * t], axis=-1)
+        col = np.where((up > 0)[..., None], sky, ground)
+        band = np.exp(-(up / 0.06) ** 2)
+        col = col + band[..., None] * np.array([0.9, 0.7, 0.45])
+        n1 = value_noise3(d * 6.0 + 17.0, seed)
+        n2 = value_noise3(d * 23.0 + 5.0, seed ^ 0x9E3779B9)
+        col = col * (0.6 + 0.5 * n1 + 0.3 * n2)[..., None]
+        cs = d @ SUN_DIR
+        ang = np.arccos(np.clip(cs, -1, 1))
+        sun = 5.0e4 * np.exp(-(ang / 0.012) ** 4) + 40.0 * np.exp(-(ang / 0.08) ** 2)
+        col = col + sun[..., None] * np.array([1.0, 0.92, 0.8])
+        if rgbe_roundtrip:
+            out[y0:y1] = rgbe_decode(rgbe_encode(col))
+        else:
+            out[y0:y1, :, :3] = col.astype(np.float32)
+            out[y0:y1, :, 3] = 1.0
     return out
+
+
+def synth_env(W, seed=0x5EED0001, rgbe_roundtrip=True, chunk_rows=256, workers=1):
+    """Procedural HDR cube [6][W][W][4] float32: sky gradient + sun disc (peak 5e4) + horizon band
+    + value noise, round-tripped through RGBE so the values are what stbi_loadf would return.
+    workers > 1 computes the six faces in separate processes (same result)."""
+    jobs = [(W, seed, rgbe_roundtrip, f, chunk_rows) for f in range(6)]
+    if workers > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(6, workers)) as pool:
+            faces = pool.map(_env_face, jobs)
+    else:
+        faces = [_env_face(j) for j in jobs]
+    return np.stack(faces, axis=0)
 
 
 def env_to_hdr_strip(env, rle=True):
