@@ -1,0 +1,220 @@
+"""CPU tests (no GPU) of the product's host side: the C ABI exports every declared symbol, the host tables,
+the RGBE decoder, the camera/Globals code, the work partitioner (incl. a 2-rank gloo run)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    import pbrhip
+    if not os.path.exists(pbrhip.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(pbrhip.PKG_ROOT, "csrc"), "-j", "8"], stdout=subprocess.DEVNULL)
+    return pbrhip.lib()
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"^\s*#\s*define.*$", "", text, flags=re.M)
+    names = set(re.findall(r"\b((?:GPU|GPUX|PBR|pbrk)_[A-Za-z0-9_]+)\s*\(", text))
+    return {n for n in names if not n.startswith(("GPU_STR", "GPU_LangAgnosticLiteral"))}
+
+
+def test_library_exports_every_declared_symbol(L):
+    """include/*.h <-> libgpu_hip.so <-> the ctypes prototype table agree (no compute calls)."""
+    import pbrhip
+    inline = {"GPU_Read", "GPU_Write", "GPU_ReadWrite", "GPU_GetFormatInfo"}
+    declared = set()
+    for h in ("gpu_hip.h", "gpux.h", "pbr_host.h", "pbr_kernels.h"):
+        declared |= declared_functions(h)
+    declared -= inline
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} is declared in include/ but not exported by libgpu_hip.so"
+        assert name in pbrhip.PROTOTYPES, f"{name} has no ctypes prototype"
+    assert L.GPUX_BackendName() == b"hip-gfx950"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", pbrhip.LIB_PATH], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert declared <= exported
+
+
+def test_header_enums_keep_reference_numbering():
+    """Enum values are ABI (callers pass them by value)."""
+    src = "#include \"gpux.h\"\n#include <stdio.h>\nint main(){printf(\"%d %d %d %d %d %d %d %d %zu %zu %zu\\n\", GPU_Format_RGBA8UN, GPU_Format_RG16F," \
+          " GPU_Format_RGBA16F, GPU_Format_RGBA32F, GPU_Format_D32F_Or_X8D24UN, GPU_Format_BC5_UN, GPU_TextureFlag_Cubemap, GPU_BufferFlag_StorageBuffer," \
+          " sizeof(GPU_Texture), sizeof(GPU_Buffer), sizeof(GPU_ShaderDesc)); return 0;}\n"
+    exe = "/tmp/pbr_enum_check"
+    subprocess.run(["gcc", "-std=c11", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src, text=True, check=True)
+    vals = subprocess.check_output([exe], text=True).split()
+    assert vals == ["3", "6", "8", "12", "23", "29", "8", "4", "28", "16", "80"]
+
+
+def test_host_tables_match_oracle(L):
+    import pbr_oracle as O
+    n = 8192
+    ang = np.zeros((n, 4), np.float32)
+    L.pbrk_host_sample_angles(n, ang.ctypes.data_as(C.c_void_p))
+    ref = np.zeros((n, 4), np.float32)
+    O.lib().orc_sample_angles(n, ref.reshape(-1))
+    assert np.array_equal(ang, ref)
+    for rough, nz_expected in ((0.03, 1389), (0.15, 8192), (0.4, 8192), (0.6, 8192)):
+        tab = np.zeros((n, 4), np.float32)
+        alpha = C.c_float()
+        cnt = L.pbrk_host_prefilter_table(n, C.c_float(rough), tab.ctypes.data_as(C.c_void_p), C.byref(alpha))
+        assert cnt == nz_expected                         # only i <= 1388 non-zero at m = .03
+        D = np.zeros(n, np.float32)
+        O.lib().orc_prefilter_D(n, rough, D)
+        dw = np.float32(2.0) * np.float32(3.14159265358979323846) / np.float32(n)
+        w = (D * ref[:, 0]) * dw
+        nz = np.nonzero(w)[0]
+        assert len(nz) == cnt and np.array_equal(tab[:cnt, 3], w[nz])
+        assert np.allclose(np.linalg.norm(tab[:cnt, :3], axis=1), 1.0, atol=1e-6)
+        # alpha = what the shader accumulates in its alpha lane
+        want_alpha = O.prefilter_mip(None, 1, 16, 1, roughness=rough, faces=(0, 1), rows=(0, 1))[0, 0, 0, 3]
+        assert alpha.value == want_alpha
+    irr = np.zeros((1024, 4), np.float32)
+    assert L.pbrk_host_irradiance_table(1024, irr.ctypes.data_as(C.c_void_p)) == 1024
+    assert np.allclose(irr[:, 3], 1 - np.arange(1024) / 1024.0, atol=3e-7) and np.array_equal(irr[:, 2], irr[:, 3])
+
+
+def test_pyramid_layout_helpers(L):
+    import pbr_oracle as O
+    for W in (1, 2, 64, 2048):
+        levels = L.pbrk_mip_count(W, W)
+        assert levels == O.mip_count(W)
+        for l in range(levels + 1):
+            assert L.pbrk_level_offset(W, l) * 4 == O.level_offset(W, l)
+        assert L.pbrk_bordered_pyramid_texels(W, levels) == sum(6 * (max(1, W >> l) + 2) ** 2 for l in range(levels))
+
+
+def test_product_rgbe_decoder(L, golden_dir):
+    """PBR_DecodeHDR (host/pbr_rgbe.c) against the reference's stb_image output and hand-made edge cases."""
+    from pbrhip import synth
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+
+    def decode(data):
+        w, h, err = C.c_int(), C.c_int(), C.c_char_p()
+        p = L.PBR_DecodeHDR(data, len(data), C.byref(w), C.byref(h), C.byref(err))
+        if not p:
+            return None, err.value
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(h.value, w.value, 4)).copy()
+        libc.free(p)
+        return arr, None
+
+    z = np.load(os.path.join(golden_dir, "ref_stb_hdr_decode.npz"))
+    for key in ("file_rle", "file_flat"):
+        got, err = decode(z[key].tobytes())
+        assert err is None and np.array_equal(got, z["decoded"])
+    rng = np.random.default_rng(11)
+    px = rng.integers(0, 256, (5, 4, 4), dtype=np.uint8)          # width < 8: flat only
+    got, _ = decode(synth.hdr_file_bytes(px, rle=True))
+    assert np.array_equal(got, synth.rgbe_decode(px))
+    assert decode(b"#?RADIANCE\nFORMAT=32-bit_rle_xyze\n\n-Y 1 +X 1\n\0\0\0\0")[0] is None       # unsupported format
+    assert decode(b"P6\n1 1\n255\n\0\0\0")[0] is None                                           # not an HDR
+    assert decode(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n+Y 1 +X 1\n\0\0\0\0")[0] is None       # unsupported orientation
+    bad = bytearray(synth.hdr_file_bytes(rng.integers(0, 256, (2, 16, 4), dtype=np.uint8), rle=True))
+    bad[-40] = 0xFF                                              # corrupt a run length
+    arr, err = decode(bytes(bad))
+    assert arr is None or arr.shape == (2, 16, 4)                # must not crash; error or garbage-but-bounded
+
+
+def test_fill_globals_matches_reference_handmade_math(L, golden_dir):
+    import pbrhip
+    z = np.load(os.path.join(golden_dir, "ref_globals_poses.npz"))
+    for k in range(len(z["globals"])):
+        fov, aspect, near, far, sx, sy, frame = z["params"][k]
+        ori = None if z["default_ori"][k] else z["ori"][k]
+        g = pbrhip.fill_globals(z["pos"][k], ori, fov, aspect, near, far, (sx, sy), int(frame))
+        got = np.frombuffer(bytes(g), np.float32)[:137]
+        want = z["globals"][k][:137]
+        scale = np.maximum(np.abs(want).reshape(-1), 1e-3)
+        # matrices: fp32 rounding of a different-but-equivalent op order; the inverse-projection entries are ~250 with 1e-5 abs noise
+        assert np.all(np.abs(got - want) <= 2e-5 * np.maximum(scale, 1.0)), k
+    g0 = pbrhip.fill_globals((0, 0, 5))
+    assert np.allclose(list(g0.sun_direction)[:3], (-0.827670276, -0.101625085, -0.551936984), atol=1e-6)
+    wfc = np.array(list(g0.world_space_from_clip)).reshape(4, 4)
+    assert np.allclose(wfc[0], (1.36413682, 0, 0, 0), atol=1e-6) and np.allclose(wfc[3], (0, 0.999999881, 250.000015, 50.0000038), rtol=1e-6)
+
+
+def units_of(specular, min_size, irr, env, world, rank):
+    import pbrhip
+    arr, n = pbrhip.partition(specular, min_size, irr, env, world, rank)
+    return [(arr[i].kind, arr[i].mip, arr[i].face0, arr[i].face1, arr[i].row0, arr[i].row1, arr[i].cost) for i in range(n)]
+
+
+def test_partition_covers_every_texel_once_and_balances(L):
+    for (spec, irr, world) in ((4096, 128, 8), (512, 32, 2), (64, 16, 3), (256, 32, 1)):
+        mips = int(np.log2(spec)) + 1
+        cover = {("p", m): np.zeros((6, max(1, spec >> m)), np.int32) for m in range(mips)}
+        cover[("i", 0)] = np.zeros((6, irr), np.int32)
+        loads = []
+        for r in range(world):
+            us = units_of(spec, 1, irr, 2048, world, r)
+            loads.append(sum(u[6] for u in us))
+            for (kind, mip, f0, f1, r0, r1, cost) in us:
+                key = ("i", 0) if kind == 1 else ("p", mip)
+                cover[key][f0:f1, r0:r1] += 1
+        for k, c in cover.items():
+            assert np.all(c == 1), (spec, world, k)
+        assert max(loads) <= 1.08 * (sum(loads) / world), (spec, world, loads)     # cost balance
+        # rank < 0 lists everything; partition is deterministic
+        assert len(units_of(spec, 1, irr, 2048, world, -1)) == sum(len(units_of(spec, 1, irr, 2048, world, r)) for r in range(world))
+        assert units_of(spec, 1, irr, 2048, world, 0) == units_of(spec, 1, irr, 2048, world, 0)
+    # reference stop rule: `if (size < 16) break;` (render.cpp:566)
+    assert {u[1] for u in units_of(256, 16, 0, 256, 1, 0)} == {0, 1, 2, 3, 4}
+
+
+GLOO_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.path.join(sys.argv[1], "vulkan-pbr-renderer_amd", "python"))
+import numpy as np, torch, torch.distributed as dist
+import pbrhip
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+spec, irr = 64, 16
+L = pbrhip.lib()
+mips = L.pbrk_mip_count(spec, spec)
+total = L.pbrk_pyramid_texels(spec, mips) * 4
+mem = torch.zeros(total, dtype=torch.float32)
+def sl(u):
+    size = max(1, spec >> u.mip); base = L.pbrk_level_offset(spec, u.mip) * 4
+    return mem[base + ((u.face0 * size + u.row0) * size) * 4: base + (((u.face1 - 1) * size + u.row1) * size) * 4]
+mine, n = pbrhip.partition(spec, 1, 0, 64, world, rank)
+for i in range(n):                      # "compute": stamp each owned tile with rank+1
+    sl(mine[i]).fill_(float(rank + 1))
+ops = []
+if rank == 0:
+    for r in range(1, world):
+        us, m = pbrhip.partition(spec, 1, 0, 64, world, r)
+        ops += [dist.P2POp(dist.irecv, sl(us[i]), r) for i in range(m)]
+else:
+    ops = [dist.P2POp(dist.isend, sl(mine[i]), 0) for i in range(n)]
+for w in dist.batch_isend_irecv(ops):
+    w.wait()
+if rank == 0:
+    assert torch.all(mem > 0), "some texel was never produced"
+    counts = [int((mem == r + 1).sum()) for r in range(world)]
+    assert sum(counts) == total and min(counts) > 0
+    print("GATHER_OK", counts)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_gather(L, tmp_path):
+    """The N>1 data path of bench.py (partition -> per-rank tiles -> one grouped send/recv gather to rank 0) on CPU."""
+    script = tmp_path / "gloo_worker.py"
+    script.write_text(GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "GATHER_OK" in out.stdout
