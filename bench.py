@@ -286,6 +286,11 @@ def main():
         except Exception as e:      # the headline number must not depend on the extra
             extra["shade_error"] = repr(e)
 
+    if os.environ.get("PBR_MC_STATS") == "1":
+        st = (C.c_uint64 * 2)()
+        if L.pbrk_mc_stats(st) == 0 and st[1]:
+            extra["mc_binned_fallback_fraction"] = st[0] / st[1]
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(env, W, spec_size, irr_size)

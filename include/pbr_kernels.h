@@ -86,9 +86,16 @@ int pbrk_prefilter_copy(const void* src_bordered_level, int n_src, void* out, in
  * out.rgb = (sum_i w_i * bilinear(src, frame(texel) * l_i)) / divisor ; out.a = alpha.
  * Prefilter (gen_prefiltered_env_map.glsl:115-146): table from pbrk_host_prefilter_table, divisor PI.
  * Irradiance (gen_irradiance_map.glsl:81-97): table from pbrk_host_irradiance_table, divisor N, alpha 0. */
-int pbrk_mc_filter(const void* src_bordered_level, int n_src, const void* table4, int n_entries,
+/* src_cells (optional, may be NULL): the same level in the 2x2-footprint "cells" layout built by pbrk_cells_build
+ * (48 B per tap position, 3 loads per sample instead of 4; the vector-memory instruction rate bounds this kernel). */
+size_t pbrk_cells_bytes(int n_src);
+int pbrk_cells_build(const void* bordered_level, int n_src, void* cells, void* stream);
+int pbrk_mc_filter(const void* src_bordered_level, const void* src_cells, int n_src, const void* table4, int n_entries,
                    float divisor, float alpha, void* out, int out_size,
                    int face0, int face1, int y0, int y1, void* stream);
+
+/* tuning aid (PBR_MC_STATS=1): {wave-samples served by the direct-load fallback, all wave-samples} of the binned K4b kernel */
+int pbrk_mc_stats(unsigned long long* out2);
 
 /* ---- K5: deferred shade pass (shaders/lighting_pass.glsl:432-716, in-scope sub-blocks). */
 typedef struct PbrkShadeArgs {

@@ -65,6 +65,8 @@ struct TextureImpl {
     size_t bordered_bytes = 0;
     bool bordered_valid = false;
     bool owns_memory = true;          // false: GPUX_MakeTextureExternal (caller-owned HBM, e.g. a torch tensor)
+    std::map<int, void*> cells;       // per-level 2x2-footprint twin used by the Monte-Carlo kernels (built on demand)
+    std::map<int, bool> cells_valid;
 };
 struct BufferImpl {
     GPU_Buffer base;
@@ -210,8 +212,8 @@ GPU_API void GPU_Init(GPU_WindowHandle window) {
 
 GPU_API void GPU_Deinit(void) {
     if (!G.init) return;
-    hipDeviceSynchronize();
-    for (auto& kv : G.tables) hipFree(kv.second.dev);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : G.tables) (void)hipFree(kv.second.dev);
     G.tables.clear();
     G.init = false;
 }
@@ -412,6 +414,7 @@ GPU_API void GPU_DestroyTexture(GPU_Texture* tex) {
     TextureImpl* t = (TextureImpl*)tex;
     if (t->owns_memory) (void)hipFree(t->dev);
     if (t->bordered) (void)hipFree(t->bordered);
+    for (auto& kv : t->cells) (void)hipFree(kv.second);
     delete t;
 }
 
@@ -439,7 +442,7 @@ GPU_API GPU_Buffer* GPU_MakeBuffer(uint32_t size, GPU_BufferFlags flags, const v
 GPU_API void GPU_DestroyBuffer(GPU_Buffer* buf) {
     if (!buf) return;
     BufferImpl* b = (BufferImpl*)buf;
-    if (b->pinned_host) hipHostFree(b->dev); else hipFree(b->dev);
+    if (b->pinned_host) (void)hipHostFree(b->dev); else (void)hipFree(b->dev);
     delete b;
 }
 
@@ -637,9 +640,9 @@ static void reset_graph(GPU_Graph* g) {
 }
 GPU_API void GPU_DestroyGraph(GPU_Graph* g) {
     GPU_REQUIRE_V(g, "GPU_DestroyGraph: NULL graph");            // the reference does not accept NULL here (gpu_vulkan.c:2393-2404)
-    hipStreamSynchronize(g->stream);
-    for (hipEvent_t e : g->ev) hipEventDestroy(e);
-    hipStreamDestroy(g->stream);
+    (void)hipStreamSynchronize(g->stream);
+    for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(g->stream);
     delete g;
 }
 
@@ -893,6 +896,7 @@ GPU_API void GPU_OpClearDepthStencil(GPU_Graph* g, GPU_Texture* dst, uint32_t mi
 // ------------------------------------------------------------------------------------------
 static bool ensure_bordered(TextureImpl* t, hipStream_t st) {
     if (t->bordered_valid) return true;
+    for (auto& kv : t->cells_valid) kv.second = false;
     int W = (int)t->base.width, levels = (int)t->base.mip_level_count;
     if (!t->bordered) {
         t->bordered_bytes = pbrk_bordered_pyramid_texels(W, levels) * 16;
@@ -902,7 +906,24 @@ static bool ensure_bordered(TextureImpl* t, hipStream_t st) {
     int rc = pbrk_border_build(t->dev, t->bordered, W, levels, st);
     if (rc != PBRK_OK) { gpu_fail("border build failed (%d)", rc); return false; }
     t->bordered_valid = true;
+    for (auto& kv : t->cells_valid) kv.second = false;
     return true;
+}
+
+// cells twin of one level (needs a valid bordered twin); NULL when the level is too big to be worth it
+static void* ensure_cells(TextureImpl* t, int level, hipStream_t st) {
+    int n = (int)t->base.width >> level; if (n < 1) n = 1;
+    if (n > 512) return nullptr;
+    if (t->cells_valid[level]) return t->cells[level];
+    void*& c = t->cells[level];
+    if (!c) {
+        hipError_t e = hipMalloc(&c, pbrk_cells_bytes(n));
+        if (e != hipSuccess) { c = nullptr; return nullptr; }
+    }
+    const void* src = (const char*)t->bordered + pbrk_bordered_level_offset((int)t->base.width, level) * 16;
+    if (pbrk_cells_build(src, n, c, st) != PBRK_OK) return nullptr;
+    t->cells_valid[level] = true;
+    return c;
 }
 
 static float reference_roughness(int mip) {                      // gen_prefiltered_env_map.glsl:117 + SURVEY 8d extension
@@ -994,9 +1015,11 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
         if ((float)l != lod && lod < (float)(levels - 1)) { gpu_fail("%s: fractional source LOD %g is not supported by the precompute kernels", nm, lod); return; }
         int n_src = W >> l; if (n_src < 1) n_src = 1;
         const void* src = (const char*)et->bordered + pbrk_bordered_level_offset(W, l) * 16;
+        const void* cells = nullptr;
+        if (!copy) { bool had = et->cells_valid[l]; if (had) cells = et->cells[l]; else timed(g, "cells.env", ev_used, [&] { cells = ensure_cells(et, l, st); }); }
         timed(g, nm, ev_used, [&] {
             int rc = copy ? pbrk_prefilter_copy(src, n_src, out_ptr, (int)size, (int)op.face0, (int)op.face1, (int)op.row0, (int)op.row1, st)
-                          : pbrk_mc_filter(src, n_src, tab->dev, tab->count, divisor, alpha, out_ptr, (int)size,
+                          : pbrk_mc_filter(src, cells, n_src, tab->dev, tab->count, divisor, alpha, out_ptr, (int)size,
                                            (int)op.face0, (int)op.face1, (int)op.row0, (int)op.row1, st);
             if (rc != PBRK_OK) gpu_fail("%s launch failed (%d)", nm, rc);
         });

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
         f3 sun_emission = mk3(25.0f * 1.0f, 25.0f * 0.9f, 25.0f * 0.7f);               // :616
         f3 outl = mk3(0.0f, 0.0f, 0.0f);
 
-        bool sky = (fminf(fmaxf(P.x, -99.0f), 99.0f) != P.x) | (fminf(fmaxf(P.y, -99.0f), 99.0f) != P.y) |
+        bool sky = (fminf(fmaxf(P.x, -99.0f), 99.0f) != P.x) || (fminf(fmaxf(P.y, -99.0f), 99.0f) != P.y) ||
                    (fminf(fmaxf(P.z, -99.0f), 99.0f) != P.z);                          // :708
 
         if ((p.flags & PBRK_SHADE_SHAFTS) && !sky) {                                   // :622-651 (visibility == 1)

@@ -240,8 +240,8 @@ uint32_t PBR_PartitionIBL(uint32_t specular_size, uint32_t min_size, uint32_t ir
             uint32_t rows_per_tile = (uint32_t)(target / per_row);
             if (rows_per_tile < 1) rows_per_tile = 1;
             if (rows_per_tile > size) rows_per_tile = size;
-            /* keep tiles a multiple of 8 rows where possible (kernel tile height) */
-            if (rows_per_tile >= 8) rows_per_tile &= ~7u;
+            /* keep tiles a multiple of 16 rows where possible (kernel tile height) */
+            if (rows_per_tile >= 16) rows_per_tile &= ~15u;
             for (uint32_t f = 0; f < 6; ++f)
                 for (uint32_t r = 0; r < size; r += rows_per_tile) {
                     if (pass == 1) {

@@ -165,8 +165,10 @@ PROTOTYPES = {
     "pbrk_border_build": (C.c_int, [VP, VP, C.c_int, C.c_int, VP]),
     "pbrk_brdf_lut": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, VP]),
     "pbrk_prefilter_copy": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
-    "pbrk_mc_filter": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_float, C.c_float, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "pbrk_mc_filter": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, C.c_float, C.c_float, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "pbrk_cells_bytes": (C.c_size_t, [C.c_int]), "pbrk_cells_build": (C.c_int, [VP, C.c_int, VP, VP]),
     "pbrk_shade": (C.c_int, [C.POINTER(PbrkShadeArgs), VP]),
+    "pbrk_mc_stats": (C.c_int, [C.POINTER(C.c_uint64)]),
 }
 
 _LIB = None
