@@ -112,12 +112,20 @@ typedef struct PbrkShadeArgs {
     int prefiltered_size, prefiltered_levels;
     const void* lut;                    /* half2 [S][S] */
     int lut_size;
+    /* optional gather-saving twins (NULL = not available): cells of the irradiance level; cells of the prefiltered
+     * levels >= prefiltered_cells_first (back to back, pbrk_cells_bytes each); 2x2-footprint cells of the LUT */
+    const void* irradiance_cells;
+    const void* prefiltered_cells;
+    int prefiltered_cells_first;
+    const void* lut_cells;              /* uint4 [(S+1)][(S+1)]: {t00,t10,t01,t11} half2, tap origin (-1,-1), clamp-to-edge */
     void* out;                          /* half4 or float4 [H][W] */
     int out_format;                     /* PBRK_FMT_RGBA16F / PBRK_FMT_RGBA32F */
     int flags;                          /* PBRK_SHADE_* */
     float globals[138];                 /* RendererGlobalsBuffer, render.h:122-136 (552 bytes) */
 } PbrkShadeArgs;
 int pbrk_shade(const PbrkShadeArgs* args, void* stream);
+/* LUT twin for K5: one 16-byte load per bilinear LUT fetch */
+int pbrk_lut_cells_build(const void* lut_half2, int size, void* cells_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -234,3 +234,30 @@ def test_sharded_units_equal_full_dispatch(gpu, env64):
     assert np.array_equal(pbrhip.read_mip(irr_full, 0).view(np.uint32), pbrhip.read_mip(maps.irradiance_map, 0).view(np.uint32))
     L.GPU_DestroyGraph(g); L.GPU_DestroyDescriptorArena(arena); L.PBR_DestroyIBLPipelines(pipes)
     L.PBR_DestroyIBLMaps(C.byref(maps)); L.GPU_DestroyTexture(full); L.GPU_DestroyTexture(irr_full)
+
+
+def test_shade_random_bytes_all_decodes(gpu):
+    """Every unorm8 value in every channel (exact b/255 decode), non-unit normals, random depths incl. sky."""
+    import pbrhip, pbr_oracle as O
+    W, H = 96, 64
+    gbd, env_tex, maps, gb, lp, glob = _shade_setup(gpu, W, H, pbrhip.Format_RGBA32F)
+    rng = np.random.default_rng(0x5EED00AE)
+    for key in ("base", "normal", "orm", "emissive"):
+        gbd[key] = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    gbd["base"][0, :256 % W] = 0
+    gbd["orm"][1, :, 1] = np.arange(W, dtype=np.uint8) * 2            # a roughness ramp
+    gbd["emissive"][rng.random((H, W)) > 0.1] = 0
+    gbd["depth"] = (0.9980 + 0.0019 * rng.random((H, W))).astype(np.float32)
+    gbd["depth"][rng.random((H, W)) < 0.15] = 1.0
+    for name, key in (("base_color", "base"), ("normal", "normal"), ("orm", "orm"), ("emissive", "emissive"), ("depth", "depth")):
+        pbrhip.upload_mip(getattr(gb, name), 0, gbd[key])
+    glob = pbrhip.fill_globals((0, 0, 5), aspect=W / H, frame_idx=17)
+    g = gpu.GPU_MakeGraph()
+    gpu.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
+    gpu.GPU_GraphSubmit(g); gpu.GPU_GraphWait(g)
+    got = pbrhip.read_mip(gb.lighting_result, 0)
+    want = _oracle_shade(gpu, gbd, maps, glob, O.SHADE_IBL)
+    assert not np.isnan(got).any()
+    assert rel_err(got[..., :3], want[..., :3], floor=1e-2) < REL, rel_err(got[..., :3], want[..., :3], floor=1e-2)
+    gpu.GPU_DestroyGraph(g); gpu.PBR_DestroyLightingPass(lp); gpu.PBR_DestroyGBuffer(C.byref(gb))
+    gpu.PBR_DestroyIBLMaps(C.byref(maps)); gpu.GPU_DestroyTexture(env_tex)

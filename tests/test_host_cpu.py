@@ -218,3 +218,16 @@ def test_two_rank_gloo_gather(L, tmp_path):
                           "--master-port", "29533", str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "GATHER_OK" in out.stdout
+
+
+def test_unorm8_decode_trick():
+    """k_shade.hip decodes unorm8 as fma(fma(-255, q, b), rc, q) with q = b*rc, rc = fl(1/255): equal to the correctly
+    rounded b/255.0f (what the shader's texture fetch returns) for all 256 inputs, while b*rc alone is not."""
+    b = np.arange(256, dtype=np.float32)
+    want = b / np.float32(255.0)
+    rc = np.float32(1.0) / np.float32(255.0)
+    q = b * rc
+    r = (b.astype(np.float64) - 255.0 * q.astype(np.float64)).astype(np.float32)          # fma(-255, q, b): exact
+    q2 = (r.astype(np.float64) * np.float64(rc) + q.astype(np.float64)).astype(np.float32)  # fma(r, rc, q)
+    assert np.array_equal(q2, want)
+    assert (q != want).sum() > 0

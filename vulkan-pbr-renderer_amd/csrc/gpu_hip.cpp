@@ -65,8 +65,9 @@ struct TextureImpl {
     size_t bordered_bytes = 0;
     bool bordered_valid = false;
     bool owns_memory = true;          // false: GPUX_MakeTextureExternal (caller-owned HBM, e.g. a torch tensor)
-    std::map<int, void*> cells;       // per-level 2x2-footprint twin used by the Monte-Carlo kernels (built on demand)
-    std::map<int, bool> cells_valid;
+    // 2x2-footprint "cells" twin of the levels with n <= 512 (levels cells_first.., back to back), built per level on demand
+    void* cells = nullptr; int cells_first = 0; std::vector<size_t> cells_off; std::vector<char> cells_valid;
+    void* lut_cells = nullptr; bool lut_cells_valid = false;      // RG16F 2-D textures sampled by the shade pass
 };
 struct BufferImpl {
     GPU_Buffer base;
@@ -414,7 +415,8 @@ GPU_API void GPU_DestroyTexture(GPU_Texture* tex) {
     TextureImpl* t = (TextureImpl*)tex;
     if (t->owns_memory) (void)hipFree(t->dev);
     if (t->bordered) (void)hipFree(t->bordered);
-    for (auto& kv : t->cells) (void)hipFree(kv.second);
+    if (t->cells) (void)hipFree(t->cells);
+    if (t->lut_cells) (void)hipFree(t->lut_cells);
     delete t;
 }
 
@@ -896,7 +898,7 @@ GPU_API void GPU_OpClearDepthStencil(GPU_Graph* g, GPU_Texture* dst, uint32_t mi
 // ------------------------------------------------------------------------------------------
 static bool ensure_bordered(TextureImpl* t, hipStream_t st) {
     if (t->bordered_valid) return true;
-    for (auto& kv : t->cells_valid) kv.second = false;
+    for (char& v : t->cells_valid) v = 0;
     int W = (int)t->base.width, levels = (int)t->base.mip_level_count;
     if (!t->bordered) {
         t->bordered_bytes = pbrk_bordered_pyramid_texels(W, levels) * 16;
@@ -906,24 +908,38 @@ static bool ensure_bordered(TextureImpl* t, hipStream_t st) {
     int rc = pbrk_border_build(t->dev, t->bordered, W, levels, st);
     if (rc != PBRK_OK) { gpu_fail("border build failed (%d)", rc); return false; }
     t->bordered_valid = true;
-    for (auto& kv : t->cells_valid) kv.second = false;
+    for (char& v : t->cells_valid) v = 0;
     return true;
 }
 
-// cells twin of one level (needs a valid bordered twin); NULL when the level is too big to be worth it
+// cells twin of one level (needs a valid bordered twin); NULL when the level is too big to be worth it (n > 512)
 static void* ensure_cells(TextureImpl* t, int level, hipStream_t st) {
-    int n = (int)t->base.width >> level; if (n < 1) n = 1;
-    if (n > 512) return nullptr;
-    if (t->cells_valid[level]) return t->cells[level];
-    void*& c = t->cells[level];
-    if (!c) {
-        hipError_t e = hipMalloc(&c, pbrk_cells_bytes(n));
-        if (e != hipSuccess) { c = nullptr; return nullptr; }
+    int W = (int)t->base.width, levels = (int)t->base.mip_level_count;
+    if (t->cells_off.empty()) {
+        int first = 0;
+        while (first < levels && (W >> first) > 512) ++first;
+        t->cells_first = first;
+        size_t off = 0;
+        for (int l = first; l < levels; ++l) { t->cells_off.push_back(off); int n = W >> l; if (n < 1) n = 1; off += pbrk_cells_bytes(n); }
+        t->cells_off.push_back(off);
+        t->cells_valid.assign(levels > first ? levels - first : 0, 0);
+        if (off) {
+            hipError_t e = hipMalloc(&t->cells, off);
+            if (e != hipSuccess) { t->cells = nullptr; gpu_fail("cells twin allocation (%zu bytes) failed: %s", off, hipGetErrorString(e)); }
+        }
     }
-    const void* src = (const char*)t->bordered + pbrk_bordered_level_offset((int)t->base.width, level) * 16;
+    if (!t->cells || level < t->cells_first || level >= levels) return nullptr;
+    int li = level - t->cells_first;
+    void* c = (char*)t->cells + t->cells_off[li];
+    if (t->cells_valid[li]) return c;
+    int n = W >> level; if (n < 1) n = 1;
+    const void* src = (const char*)t->bordered + pbrk_bordered_level_offset(W, level) * 16;
     if (pbrk_cells_build(src, n, c, st) != PBRK_OK) return nullptr;
-    t->cells_valid[level] = true;
+    t->cells_valid[li] = 1;
     return c;
+}
+static bool cells_ready(TextureImpl* t, int level) {
+    return t->cells && level >= t->cells_first && level - t->cells_first < (int)t->cells_valid.size() && t->cells_valid[level - t->cells_first];
 }
 
 static float reference_roughness(int mip) {                      // gen_prefiltered_env_map.glsl:117 + SURVEY 8d extension
@@ -976,7 +992,7 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
                 int rc = pbrk_brdf_lut(out_ptr, fmt, (int)size, n, ang->dev, vcs->dev, (int)op.row0, (int)op.row1, st);
                 if (rc != PBRK_OK) gpu_fail("K1 launch failed (%d)", rc);
             });
-            ot->bordered_valid = false;
+            ot->bordered_valid = false; ot->lut_cells_valid = false;
             return;
         }
         Slot* env = named_slot(op.set, "TEX_ENV_CUBE");
@@ -1016,7 +1032,7 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
         int n_src = W >> l; if (n_src < 1) n_src = 1;
         const void* src = (const char*)et->bordered + pbrk_bordered_level_offset(W, l) * 16;
         const void* cells = nullptr;
-        if (!copy) { bool had = et->cells_valid[l]; if (had) cells = et->cells[l]; else timed(g, "cells.env", ev_used, [&] { cells = ensure_cells(et, l, st); }); }
+        if (!copy) { if (cells_ready(et, l)) cells = ensure_cells(et, l, st); else timed(g, "cells.env", ev_used, [&] { cells = ensure_cells(et, l, st); }); }
         timed(g, nm, ev_used, [&] {
             int rc = copy ? pbrk_prefilter_copy(src, n_src, out_ptr, (int)size, (int)op.face0, (int)op.face1, (int)op.row0, (int)op.row1, st)
                           : pbrk_mc_filter(src, cells, n_src, tab->dev, tab->count, divisor, alpha, out_ptr, (int)size,
@@ -1042,14 +1058,28 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
         TextureImpl* pre = named_slot(s, "PREFILTERED_ENV_MAP")->tex;
         if (!pre->bordered_valid) { timed(g, "apron.prefiltered", ev_used, [&] { ensure_bordered(pre, g->stream); }); if (!pre->bordered_valid) return; }
         a.prefiltered_bordered = pre->bordered; a.prefiltered_size = (int)pre->base.width; a.prefiltered_levels = (int)pre->base.mip_level_count;
+        {
+            bool all = true;
+            for (int l = 0; l < (int)pre->base.mip_level_count; ++l) if (((int)pre->base.width >> l) <= 512 && !cells_ready(pre, l)) all = false;
+            auto build = [&] { for (int l = 0; l < (int)pre->base.mip_level_count; ++l) if (((int)pre->base.width >> l) <= 512) ensure_cells(pre, l, g->stream); };
+            if (all) build(); else timed(g, "cells.prefiltered", ev_used, build);
+            a.prefiltered_cells = pre->cells; a.prefiltered_cells_first = pre->cells_first;
+        }
         a.flags = 0;
         if (op.gpipe->shade_flags & GPUX_Shade_IBL) {
             a.flags |= PBRK_SHADE_IBL;
             TextureImpl* irr = named_slot(s, "TEX_IRRADIANCE_MAP")->tex;
             if (!irr->bordered_valid) { timed(g, "apron.irradiance", ev_used, [&] { ensure_bordered(irr, g->stream); }); if (!irr->bordered_valid) return; }
             a.irradiance_bordered = irr->bordered; a.irradiance_size = (int)irr->base.width;
+            a.irradiance_cells = ensure_cells(irr, 0, g->stream);
             TextureImpl* lut = named_slot(s, "BRDF_INTEGRATION_MAP")->tex;
             a.lut = lut->dev; a.lut_size = (int)lut->base.width;
+            if (!lut->lut_cells_valid) {
+                size_t bytes = (size_t)(a.lut_size + 1) * (a.lut_size + 1) * 16;
+                if (!lut->lut_cells && hipMalloc(&lut->lut_cells, bytes) != hipSuccess) lut->lut_cells = nullptr;
+                if (lut->lut_cells && pbrk_lut_cells_build(lut->dev, a.lut_size, lut->lut_cells, g->stream) == PBRK_OK) lut->lut_cells_valid = true;
+            }
+            a.lut_cells = lut->lut_cells_valid ? lut->lut_cells : nullptr;
         }
         if (op.gpipe->shade_flags & GPUX_Shade_LightShafts) a.flags |= PBRK_SHADE_SHAFTS;
         a.out = target->dev;
@@ -1094,7 +1124,7 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
             HIP_OK(hipMemcpyAsync((char*)op.tex->dev + op.tex->mip_offset[op.mip] + per_layer * op.layer0, (const char*)op.buf->dev + op.off_a,
                                   per_layer * op.layer_count, hipMemcpyDefault, st));
         });
-        op.tex->bordered_valid = false;
+        op.tex->bordered_valid = false; op.tex->lut_cells_valid = false;
         return;
     }
     case Op_CopyT2B:
@@ -1134,7 +1164,7 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
                 HIP_OK(hipStreamSynchronize(st));      // the staging vector dies at scope exit
             }
         }
-        t->bordered_valid = false;
+        t->bordered_valid = false; t->lut_cells_valid = false;
         return;
     }
     }

@@ -23,11 +23,24 @@ struct ShadeParams {
     const float4* irr; int irr_size;
     const float4* pre; int pre_size, pre_levels;
     const __half2* lut; int lut_size;
+    const float4* irr_cells; const float4* pre_cells; int pre_cells_first; const uint4* lut_cells;
     void* out; int out_fmt; int flags;
-    float g[138];
+    float wfc[16];       // world_space_from_clip
+    float ssw[16];       // sun_space_from_world (light shafts only)
+    float sun[3], cam[3], frame_idx_mod_59;
 };
 
 __device__ __forceinline__ float fract_(float x) { return x - floorf(x); }
+// EXACT b / 255.0f for b in 0..255 in 3 instructions: one Newton correction of b * fl(1/255) is the correctly
+// rounded quotient for all 256 inputs (checked exhaustively: tests/test_host_cpu.py::test_unorm8_decode_trick)
+__device__ __forceinline__ float unorm8(unsigned b) {
+    const float rc = 1.0f / 255.0f;
+    float x = (float)b;
+    float q = x * rc;
+    float r = fmaf(-255.0f, q, x);
+    return fmaf(r, rc, q);
+}
+__device__ __forceinline__ float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
 __device__ __forceinline__ float mix_(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 // EXACT: InterleavedGradientNoise, lighting_pass.glsl:119-121
 __device__ __forceinline__ float ign(float px, float py) {
@@ -39,10 +52,10 @@ __device__ __forceinline__ float ggx_d(float NdotH, float roughness) {      // :
     float n2 = NdotH * NdotH;
     float denom = (n2 * (a2 - 1.0f) + 1.0f);
     denom = PBR_PI * denom * denom;
-    return a2 / denom;
+    return a2 * __builtin_amdgcn_rcpf(denom);        // continuous term: 1-ulp reciprocal is inside the tolerance
 }
 __device__ __forceinline__ f3 fresnel_schlick(float c, f3 F0) {             // :76-79
-    float p = powf(1.0f - c, 5.0f);
+    float p = pow5(1.0f - c);          // pow(x, 5.) of the shader; within 2 ulp of powf, not a discontinuity
     return mk3(F0.x + (1.0f - F0.x) * p, F0.y + (1.0f - F0.y) * p, F0.z + (1.0f - F0.z) * p);
 }
 __device__ __forceinline__ void mat_mul(const float* m, float x, float y, float z, float w, float* o) {
@@ -54,27 +67,53 @@ __device__ __forceinline__ int bordered_level_off(int W, int level) {
     for (int l = 0; l < level; ++l) { int n = max(W >> l, 1) + 2; off += 6 * n * n; }
     return off;
 }
+__device__ __forceinline__ int cells_level_off(int W, int first, int level) {
+    int off = 0;
+    for (int l = first; l < level; ++l) { int n = max(W >> l, 1) + 1; off += 6 * n * n * 3; }
+    return off;
+}
+__device__ __forceinline__ f3 level_fetch(const float4* __restrict__ pyr, const float4* __restrict__ cells, int cells_first,
+                                          int W, int l, int face, float s, float t) {
+    int n = max(W >> l, 1);
+    CubeTap tp = cube_tap_from_st(face, s, t, n);
+    if (cells && l >= cells_first) return fetch_rgb_cells_tap(cells + cells_level_off(W, cells_first, l), n, tp);
+    return fetch_rgb_tap(pyr + bordered_level_off(W, l), n, tp);
+}
 // trilinear fetch from a bordered pyramid (sampler: linear mip filter, LOD clamped to the chain)
-__device__ __forceinline__ f3 pyramid_fetch(const float4* __restrict__ pyr, int W, int levels, f3 d, float lod) {
+__device__ __forceinline__ f3 pyramid_fetch(const float4* __restrict__ pyr, const float4* __restrict__ cells, int cells_first,
+                                            int W, int levels, f3 d, float lod) {
+    CubeST cs = cube_select(d);
+    float s, t;
+    cube_st_exact(cs, &s, &t);
     float maxl = (float)(levels - 1);
     lod = fminf(fmaxf(lod, 0.0f), maxl);
     float fl = floorf(lod);
     int l0 = (int)fl;
     float w = lod - fl;
-    f3 c0 = cube_fetch_rgb<true>(pyr + bordered_level_off(W, l0), max(W >> l0, 1), d);
+    f3 c0 = level_fetch(pyr, cells, cells_first, W, l0, cs.face, s, t);
     if (w > 0.0f) {
         int l1 = min(l0 + 1, levels - 1);
-        f3 c1 = cube_fetch_rgb<true>(pyr + bordered_level_off(W, l1), max(W >> l1, 1), d);
+        f3 c1 = level_fetch(pyr, cells, cells_first, W, l1, cs.face, s, t);
         c0.x = lerp_fma(c0.x, c1.x, w); c0.y = lerp_fma(c0.y, c1.y, w); c0.z = lerp_fma(c0.z, c1.z, w);
     }
     return c0;
 }
 
-__device__ __forceinline__ float2 lut_fetch(const __half2* __restrict__ lut, int S, float u, float v) {
+__device__ __forceinline__ float2 lut_fetch(const __half2* __restrict__ lut, const uint4* __restrict__ cells, int S, float u, float v) {
     float fx = u * (float)S - 0.5f, fy = v * (float)S - 0.5f;
     float flx = floorf(fx), fly = floorf(fy);
     float a = fx - flx, b = fy - fly;
     int i0 = (int)flx, j0 = (int)fly;
+    if (cells) {
+        int ci = min(max(i0 + 1, 0), S), cj = min(max(j0 + 1, 0), S);
+        uint4 c = cells[cj * (S + 1) + ci];
+        float2 t00 = __half22float2(*reinterpret_cast<__half2*>(&c.x)), t10 = __half22float2(*reinterpret_cast<__half2*>(&c.y));
+        float2 t01 = __half22float2(*reinterpret_cast<__half2*>(&c.z)), t11 = __half22float2(*reinterpret_cast<__half2*>(&c.w));
+        float2 r;
+        r.x = lerp_fma(lerp_fma(t00.x, t10.x, a), lerp_fma(t01.x, t11.x, a), b);
+        r.y = lerp_fma(lerp_fma(t00.y, t10.y, a), lerp_fma(t01.y, t11.y, a), b);
+        return r;
+    }
     int i1 = min(max(i0 + 1, 0), S - 1), j1 = min(max(j0 + 1, 0), S - 1);
     i0 = min(max(i0, 0), S - 1); j0 = min(max(j0, 0), S - 1);
     float2 t00 = __half22float2(lut[j0 * S + i0]), t10 = __half22float2(lut[j0 * S + i1]);
@@ -94,26 +133,26 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
         float depth = p.depth[pi];
 
         // :433-442
-        f3 base = mk3(bb.x / 255.0f, bb.y / 255.0f, bb.z / 255.0f);
-        f3 N = mk3(nn.x / 255.0f * 2.0f - 1.0f, nn.y / 255.0f * 2.0f - 1.0f, nn.z / 255.0f * 2.0f - 1.0f);
-        float roughness = oo.y / 255.0f, metallic = oo.z / 255.0f;
-        f3 emissive = mk3(ee.x / 255.0f * 10.0f, ee.y / 255.0f * 10.0f, ee.z / 255.0f * 10.0f);
+        f3 base = mk3(unorm8(bb.x), unorm8(bb.y), unorm8(bb.z));
+        f3 N = mk3(unorm8(nn.x) * 2.0f - 1.0f, unorm8(nn.y) * 2.0f - 1.0f, unorm8(nn.z) * 2.0f - 1.0f);
+        float roughness = unorm8(oo.y), metallic = unorm8(oo.z);
+        f3 emissive = mk3(unorm8(ee.x) * 10.0f, unorm8(ee.y) * 10.0f, unorm8(ee.z) * 10.0f);
 
         // :444-451
         float fs_u = ((float)px + 0.5f) / (float)p.width, fs_v = ((float)py + 0.5f) / (float)p.height;
         float pw[4];
-        mat_mul(p.g + 32, fs_u * 2.0f - 1.0f, fs_v * 2.0f - 1.0f, depth, 1.0f, pw);   // world_space_from_clip
+        mat_mul(p.wfc, fs_u * 2.0f - 1.0f, fs_v * 2.0f - 1.0f, depth, 1.0f, pw);   // world_space_from_clip
         f3 P = mk3(pw[0] / pw[3], pw[1] / pw[3], pw[2] / pw[3]);
 
         // :456-459
         float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
-        float noise_offset = (1000 * 1.61803398875f) * p.g[135];                       // frame_idx_mod_59
+        float noise_offset = (1000 * 1.61803398875f) * p.frame_idx_mod_59;                       // frame_idx_mod_59
         float noise_1 = fract_(ign(fcx, fcy) + noise_offset);
         float noise_2 = fract_(ign(fcx + 90.0f, fcy + 20.0f) + noise_offset);
         float noise_3 = fract_(ign(fcx + 522.0f, fcy + 55.0f) + noise_offset);
 
         const float shadow = 1.0f;                                                     // :594-608 out of scope
-        f3 cam = mk3(p.g[132], p.g[133], p.g[134]);
+        f3 cam = mk3(p.cam[0], p.cam[1], p.cam[2]);
         f3 V = normalize3(sub3(cam, P));                                               // :612
         float VdotN = fmaxf(dot3(V, N), 0.0f);                                         // :613
         f3 sun_emission = mk3(25.0f * 1.0f, 25.0f * 0.9f, 25.0f * 0.7f);               // :616
@@ -122,71 +161,78 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
         bool sky = (fminf(fmaxf(P.x, -99.0f), 99.0f) != P.x) || (fminf(fmaxf(P.y, -99.0f), 99.0f) != P.y) ||
                    (fminf(fmaxf(P.z, -99.0f), 99.0f) != P.z);                          // :708
 
-        if ((p.flags & PBRK_SHADE_SHAFTS) && !sky) {                                   // :622-651 (visibility == 1)
-            float sp[4], cp4[4];
-            mat_mul(p.g + 96, P.x + N.x * 0.1f, P.y + N.y * 0.1f, P.z + N.z * 0.1f, 1.0f, sp);   // :596-597 sun_space_from_world
-            mat_mul(p.g + 96, cam.x, cam.y, cam.z, 1.0f, cp4);                          // :627
-            f3 delta = mk3(sp[0] - cp4[0], sp[1] - cp4[1], sp[2] - cp4[2]);
-            float dist = sqrtf(dot3(delta, delta));
-            const float step = 1.0f / 16.0f;
-            float travelled = 0.0f;
-            travelled += step * noise_1;                                               // :638
-            // bounded: non-sky pixels lie within +-99 world units => dist < 16 in sun space
-            for (int it = 0; it < 4096; ++it) {
-                travelled += step;
-                if (travelled > dist) break;
-                outl.x += 0.001f * 1.0f * sun_emission.x;
-                outl.y += 0.001f * 1.0f * sun_emission.y;
-                outl.z += 0.001f * 1.0f * sun_emission.z;
+        // :708-710 the sky branch replaces everything else: take it first (most waves of a frame are all-sky or all-surface)
+        if (sky) {
+            outl = pyramid_fetch(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, mk3(-V.x, -V.y, -V.z), 1.0f);
+        } else {
+            if (p.flags & PBRK_SHADE_SHAFTS) {                                   // :622-651 (visibility == 1)
+                float sp[4], cp4[4];
+                mat_mul(p.ssw, P.x + N.x * 0.1f, P.y + N.y * 0.1f, P.z + N.z * 0.1f, 1.0f, sp);   // :596-597 sun_space_from_world
+                mat_mul(p.ssw, cam.x, cam.y, cam.z, 1.0f, cp4);                          // :627
+                f3 delta = mk3(sp[0] - cp4[0], sp[1] - cp4[1], sp[2] - cp4[2]);
+                float dist = sqrtf(dot3(delta, delta));
+                const float step = 1.0f / 16.0f;
+                float travelled = 0.0f;
+                travelled += step * noise_1;                                               // :638
+                // bounded: non-sky pixels lie within +-99 world units => dist < 16 in sun space
+                for (int it = 0; it < 4096; ++it) {
+                    travelled += step;
+                    if (travelled > dist) break;
+                    outl.x += 0.001f * 1.0f * sun_emission.x;
+                    outl.y += 0.001f * 1.0f * sun_emission.y;
+                    outl.z += 0.001f * 1.0f * sun_emission.z;
+                }
             }
-        }
 
-        // :657-661
-        f3 F0 = mk3(mix_(0.04f, base.x, metallic), mix_(0.04f, base.y, metallic), mix_(0.04f, base.z, metallic));
-        f3 kS = fresnel_schlick(fmaxf(dot3(N, V), 0.0f), F0);
-        f3 kD = mk3((1.0f - kS.x) * (1.0f - metallic), (1.0f - kS.y) * (1.0f - metallic), (1.0f - kS.z) * (1.0f - metallic));
+            // :657-661
+            f3 F0 = mk3(mix_(0.04f, base.x, metallic), mix_(0.04f, base.y, metallic), mix_(0.04f, base.z, metallic));
+            f3 kS = fresnel_schlick(fmaxf(dot3(N, V), 0.0f), F0);
+            f3 kD = mk3((1.0f - kS.x) * (1.0f - metallic), (1.0f - kS.y) * (1.0f - metallic), (1.0f - kS.z) * (1.0f - metallic));
 
-        // :664-679
-        {
-            f3 L = mk3(-p.g[128], -p.g[129], -p.g[130]);
-            f3 H = normalize3(add3(L, V));
-            float NdotL = fmaxf(dot3(N, L), 0.0f);
-            if (NdotL > 0.0f) {
-                float VdotH = fmaxf(dot3(V, H), 0.0f);
-                float NdotH = fmaxf(dot3(N, H), 0.0f);
-                float D = ggx_d(NdotH, roughness);
-                float G = fminf(1.0f, fminf(2.0f * NdotH * VdotN / VdotH, 2.0f * NdotH * NdotL / VdotH));
-                f3 F = fresnel_schlick(VdotH, F0);
-                float den = fmaxf(4.0f * NdotL * VdotN, 0.0001f);
-                outl.x += shadow * (kD.x * base.x / PBR_PI + F.x * G * D / den) * sun_emission.x * NdotL;
-                outl.y += shadow * (kD.y * base.y / PBR_PI + F.y * G * D / den) * sun_emission.y * NdotL;
-                outl.z += shadow * (kD.z * base.z / PBR_PI + F.z * G * D / den) * sun_emission.z * NdotL;
+            // :664-679
+            {
+                f3 L = mk3(-p.sun[0], -p.sun[1], -p.sun[2]);
+                f3 Hs = add3(L, V);
+                f3 H = scale3(Hs, __builtin_amdgcn_rsqf(dot3(Hs, Hs)));      // feeds continuous terms only: 1-ulp rsq
+                float NdotL = fmaxf(dot3(N, L), 0.0f);
+                if (NdotL > 0.0f) {
+                    float VdotH = fmaxf(dot3(V, H), 0.0f);
+                    float NdotH = fmaxf(dot3(N, H), 0.0f);
+                    float D = ggx_d(NdotH, roughness);
+                    float rvh = __builtin_amdgcn_rcpf(VdotH);
+                    float G = fminf(1.0f, fminf(2.0f * NdotH * VdotN * rvh, 2.0f * NdotH * NdotL * rvh));
+                    f3 F = fresnel_schlick(VdotH, F0);
+                    float rden = __builtin_amdgcn_rcpf(fmaxf(4.0f * NdotL * VdotN, 0.0001f));
+                    const float rpi = 1.0f / PBR_PI;
+                    outl.x += shadow * (kD.x * base.x * rpi + F.x * G * D * rden) * sun_emission.x * NdotL;
+                    outl.y += shadow * (kD.y * base.y * rpi + F.y * G * D * rden) * sun_emission.y * NdotL;
+                    outl.z += shadow * (kD.z * base.z * rpi + F.z * G * D * rden) * sun_emission.z * NdotL;
+                }
             }
-        }
 
-        if (p.flags & PBRK_SHADE_IBL) {
-            float2 sb = lut_fetch(p.lut, p.lut_size, VdotN, fmaxf(roughness, 0.05f));  // :681
-            f3 irr = cube_fetch_rgb<true>(p.irr, p.irr_size, N);                              // :690
-            outl.x += kD.x * irr.x * base.x;                                           // :687
-            outl.y += kD.y * irr.y * base.y;
-            outl.z += kD.z * irr.z * base.z;
-            // :693-697
-            f3 I = mk3(-V.x, -V.y, -V.z);
-            float dNI = dot3(N, I);
-            f3 R = mk3(I.x - 2.0f * dNI * N.x, I.y - 2.0f * dNI * N.y, I.z - 2.0f * dNI * N.z);
-            float jr = 0.6f * roughness;
-            R = normalize3(mk3(R.x + jr * (noise_1 - 0.5f), R.y + jr * (noise_2 - 0.5f), R.z + jr * (noise_3 - 0.5f)));
-            float r2 = roughness * roughness;
-            float r4 = r2 * r2;
-            R = mk3(mix_(R.x, N.x, r4), mix_(R.y, N.y, r4), mix_(R.z, N.z, r4));
-            f3 spec = pyramid_fetch(p.pre, p.pre_size, p.pre_levels, R, roughness * 4.0f);   // :699
-            outl.x += spec.x * (F0.x * sb.x + sb.y);                                   // :702
-            outl.y += spec.y * (F0.y * sb.x + sb.y);
-            outl.z += spec.z * (F0.z * sb.x + sb.y);
-        }
+            if (p.flags & PBRK_SHADE_IBL) {
+                float2 sb = lut_fetch(p.lut, p.lut_cells, p.lut_size, VdotN, fmaxf(roughness, 0.05f));  // :681
+                f3 irr = p.irr_cells ? cube_fetch_rgb_cells<true>(p.irr_cells, p.irr_size, N) : cube_fetch_rgb<true>(p.irr, p.irr_size, N);                              // :690
+                outl.x += kD.x * irr.x * base.x;                                           // :687
+                outl.y += kD.y * irr.y * base.y;
+                outl.z += kD.z * irr.z * base.z;
+                // :693-697
+                f3 I = mk3(-V.x, -V.y, -V.z);
+                float dNI = dot3(N, I);
+                f3 R = mk3(I.x - 2.0f * dNI * N.x, I.y - 2.0f * dNI * N.y, I.z - 2.0f * dNI * N.z);
+                float jr = 0.6f * roughness;
+                R = normalize3(mk3(R.x + jr * (noise_1 - 0.5f), R.y + jr * (noise_2 - 0.5f), R.z + jr * (noise_3 - 0.5f)));
+                float r2 = roughness * roughness;
+                float r4 = r2 * r2;
+                R = mk3(mix_(R.x, N.x, r4), mix_(R.y, N.y, r4), mix_(R.z, N.z, r4));
+                f3 spec = pyramid_fetch(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, R, roughness * 4.0f);   // :699
+                outl.x += spec.x * (F0.x * sb.x + sb.y);                                   // :702
+                outl.y += spec.y * (F0.y * sb.x + sb.y);
+                outl.z += spec.z * (F0.z * sb.x + sb.y);
+            }
 
-        outl = add3(outl, emissive);                                                   // :706
-        if (sky) outl = pyramid_fetch(p.pre, p.pre_size, p.pre_levels, mk3(-V.x, -V.y, -V.z), 1.0f);   // :708-710
+            outl = add3(outl, emissive);                                                   // :706
+        }
         outl = mk3(fmaxf(outl.x, 0.0f), fmaxf(outl.y, 0.0f), fmaxf(outl.z, 0.0f));     // :712
 
         if (p.out_fmt == PBRK_FMT_RGBA16F) {
@@ -200,6 +246,23 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
             ((float4*)p.out)[pi] = make_float4(outl.x, outl.y, outl.z, 1.0f);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_lut_cells(const unsigned* __restrict__ lut, uint4* __restrict__ cells, int S) {
+    int total = (S + 1) * (S + 1);
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < total; id += gridDim.x * blockDim.x) {
+        int ci = id % (S + 1), cj = id / (S + 1);
+        int i0 = ci - 1, j0 = cj - 1;                       // tap origin; clamp-to-edge addressing
+        int ia = min(max(i0, 0), S - 1), ib = min(max(i0 + 1, 0), S - 1);
+        int ja = min(max(j0, 0), S - 1), jb = min(max(j0 + 1, 0), S - 1);
+        cells[id] = make_uint4(lut[ja * S + ia], lut[ja * S + ib], lut[jb * S + ia], lut[jb * S + ib]);
+    }
+}
+extern "C" int pbrk_lut_cells_build(const void* lut_half2, int size, void* cells_out, void* stream) {
+    if (!lut_half2 || !cells_out || size < 1) return PBRK_E_ARG;
+    int total = (size + 1) * (size + 1);
+    hipLaunchKernelGGL(k_lut_cells, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const unsigned*)lut_half2, (uint4*)cells_out, size);
+    return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
 
 extern "C" int pbrk_shade(const PbrkShadeArgs* a, void* stream) {
@@ -219,8 +282,12 @@ extern "C" int pbrk_shade(const PbrkShadeArgs* a, void* stream) {
     p.irr = (const float4*)a->irradiance_bordered; p.irr_size = a->irradiance_size;
     p.pre = (const float4*)a->prefiltered_bordered; p.pre_size = a->prefiltered_size; p.pre_levels = a->prefiltered_levels;
     p.lut = (const __half2*)a->lut; p.lut_size = a->lut_size;
+    p.irr_cells = (const float4*)a->irradiance_cells; p.pre_cells = (const float4*)a->prefiltered_cells;
+    p.pre_cells_first = a->prefiltered_cells_first; p.lut_cells = (const uint4*)a->lut_cells;
     p.out = a->out; p.out_fmt = a->out_format; p.flags = a->flags;
-    for (int i = 0; i < 138; ++i) p.g[i] = a->globals[i];
+    for (int i = 0; i < 16; ++i) { p.wfc[i] = a->globals[32 + i]; p.ssw[i] = a->globals[96 + i]; }
+    for (int i = 0; i < 3; ++i) { p.sun[i] = a->globals[128 + i]; p.cam[i] = a->globals[132 + i]; }
+    p.frame_idx_mod_59 = a->globals[135];
     long total = (long)p.w * p.h;
     int grid = (int)((total + 255) / 256);
     if (grid > 256 * 32) grid = 256 * 32;

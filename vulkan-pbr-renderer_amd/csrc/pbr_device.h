@@ -61,6 +61,7 @@ __device__ __forceinline__ f3 tangent_of(f3 R) {
 // (major axis = largest magnitude, ties z > y > x).
 struct CubeTap {
     int base;      // texel index of tap (i0, j0) inside the bordered level (face included)
+    int face, i0, j0;
     float a, b;    // bilinear weights along x and y
 };
 
@@ -69,42 +70,86 @@ struct CubeTap {
 // EXACT = true : the projection in separately rounded IEEE ops, s = (0.5*sc)/|rc| + 0.5, u = s*n - 0.5
 //                (single-sample lookups: K4a copy, shade pass) so that tap selection and weights are
 //                bit-identical to a scalar CPU evaluation even next to a 5e4:1 HDR sun texel.
-template <bool EXACT>
-__device__ __forceinline__ CubeTap cube_tap(f3 d, int n) {
-    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    int face; float sc, tc, ma;
-    if (az >= ax && az >= ay) {
-        bool neg = d.z < 0.0f; face = neg ? 5 : 4; sc = neg ? -d.x : d.x; tc = -d.y; ma = az;
-    } else if (ay >= ax) {
-        bool neg = d.y < 0.0f; face = neg ? 3 : 2; sc = d.x; tc = neg ? -d.z : d.z; ma = ay;
-    } else {
-        bool neg = d.x < 0.0f; face = neg ? 1 : 0; sc = neg ? d.z : -d.z; tc = -d.y; ma = ax;
-    }
-    float u, v;
-    if (EXACT) {
-        float s = 0.5f * sc / ma + 0.5f;
-        float t = 0.5f * tc / ma + 0.5f;
-        u = s * (float)n - 0.5f;                          // unbordered coordinate, as the sampler definition states it
-        v = t * (float)n - 0.5f;
-    } else {
-        float h = 0.5f * __builtin_amdgcn_rcpf(ma) * (float)n;   // (0.5 / |rc|) * n
-        float off = 0.5f * (float)n + 0.5f;                      // s*n - 0.5 + 1 = sc*h + n/2 + 0.5 (bordered)
-        u = fmaf(sc, h, off);
-        v = fmaf(tc, h, off);
-    }
+__device__ __forceinline__ float lerp_fma(float p, float q, float t) { return fmaf(t, q - p, p); }
+
+// Face selection uses v_cubeid/sc/tc/ma_f32: the hardware implements exactly the table above (z >= x,y first,
+// then y >= x; results are sign-flipped copies of the inputs, cubema = 2 * major axis), branch-free.
+struct CubeST { int face; float sc, tc, ma; };
+__device__ __forceinline__ CubeST cube_select(f3 d) {
+    CubeST r;
+    r.face = (int)__builtin_amdgcn_cubeid(d.x, d.y, d.z);
+    r.sc = __builtin_amdgcn_cubesc(d.x, d.y, d.z);
+    r.tc = __builtin_amdgcn_cubetc(d.x, d.y, d.z);
+    r.ma = 0.5f * fabsf(__builtin_amdgcn_cubema(d.x, d.y, d.z));      // exact: cubema = 2*major
+    return r;
+}
+// EXACT sampler coordinates s,t in [0,1] (independent of the level): s = (0.5*sc)/|rc| + 0.5
+__device__ __forceinline__ void cube_st_exact(const CubeST& c, float* s, float* t) {
+    *s = 0.5f * c.sc / c.ma + 0.5f;
+    *t = 0.5f * c.tc / c.ma + 0.5f;
+}
+__device__ __forceinline__ CubeTap cube_tap_from_st(int face, float s, float t, int n) {
+    float u = s * (float)n - 0.5f;                        // unbordered coordinate, as the sampler definition states it
+    float v = t * (float)n - 0.5f;
     float fu = floorf(u), fv = floorf(v);
-    int i0 = (int)fu + (EXACT ? 1 : 0), j0 = (int)fv + (EXACT ? 1 : 0);
-    // keep taps inside the apron whatever the input (NaN directions included)
-    i0 = min(max(i0, 0), n);
-    j0 = min(max(j0, 0), n);
-    CubeTap t;
-    t.a = u - fu; t.b = v - fv;
+    int i0 = min(max((int)fu + 1, 0), n), j0 = min(max((int)fv + 1, 0), n);   // +1: bordered layout
+    CubeTap tp;
+    tp.a = u - fu; tp.b = v - fv;
     int nb = n + 2;
-    t.base = (face * nb + j0) * nb + i0;
-    return t;
+    tp.base = (face * nb + j0) * nb + i0;
+    tp.face = face; tp.i0 = i0; tp.j0 = j0;
+    return tp;
 }
 
-__device__ __forceinline__ float lerp_fma(float p, float q, float t) { return fmaf(t, q - p, p); }
+// EXACT = false: one v_rcp_f32 + FMAs (Monte-Carlo inner loops: coordinate rounding noise averages out over
+//                thousands of samples).
+// EXACT = true : the projection in separately rounded IEEE ops, s = (0.5*sc)/|rc| + 0.5, u = s*n - 0.5
+//                (single-sample lookups: K4a copy, shade pass) so that tap selection and weights are
+//                bit-identical to a scalar CPU evaluation even next to a 5e4:1 HDR sun texel.
+template <bool EXACT>
+__device__ __forceinline__ CubeTap cube_tap(f3 d, int n) {
+    CubeST c = cube_select(d);
+    if (EXACT) {
+        float s, t;
+        cube_st_exact(c, &s, &t);
+        return cube_tap_from_st(c.face, s, t, n);
+    }
+    float h = 0.5f * __builtin_amdgcn_rcpf(c.ma) * (float)n;     // (0.5 / |rc|) * n
+    float off = 0.5f * (float)n + 0.5f;                          // s*n - 0.5 + 1 = sc*h + n/2 + 0.5 (bordered)
+    float u = fmaf(c.sc, h, off);
+    float v = fmaf(c.tc, h, off);
+    float fu = floorf(u), fv = floorf(v);
+    int i0 = min(max((int)fu, 0), n), j0 = min(max((int)fv, 0), n);
+    CubeTap tp;
+    tp.a = u - fu; tp.b = v - fv;
+    int nb = n + 2;
+    tp.base = (c.face * nb + j0) * nb + i0;
+    tp.face = c.face; tp.i0 = i0; tp.j0 = j0;
+    return tp;
+}
+
+// fetches given a precomputed tap (lets a trilinear lookup share one face selection / projection)
+__device__ __forceinline__ f3 fetch_rgb_tap(const float4* __restrict__ lvl, int n, const CubeTap& t) {
+    int nb = n + 2;
+    float4 t00 = lvl[t.base], t10 = lvl[t.base + 1];
+    float4 t01 = lvl[t.base + nb], t11 = lvl[t.base + nb + 1];
+    f3 r;
+    r.x = lerp_fma(lerp_fma(t00.x, t10.x, t.a), lerp_fma(t01.x, t11.x, t.a), t.b);
+    r.y = lerp_fma(lerp_fma(t00.y, t10.y, t.a), lerp_fma(t01.y, t11.y, t.a), t.b);
+    r.z = lerp_fma(lerp_fma(t00.z, t10.z, t.a), lerp_fma(t01.z, t11.z, t.a), t.b);
+    return r;
+}
+__device__ __forceinline__ f3 fetch_rgb_cells_tap(const float4* __restrict__ cells, int n, const CubeTap& t) {
+    int nc = n + 1;
+    const float4* c = cells + (size_t)((t.face * nc + t.j0) * nc + t.i0) * 3;
+    float4 A = c[0], Bq = c[1], Cq = c[2];
+    f3 r;
+    r.x = lerp_fma(lerp_fma(A.x, A.w, t.a), lerp_fma(Bq.z, Cq.y, t.a), t.b);
+    r.y = lerp_fma(lerp_fma(A.y, Bq.x, t.a), lerp_fma(Bq.w, Cq.z, t.a), t.b);
+    r.z = lerp_fma(lerp_fma(A.z, Bq.y, t.a), lerp_fma(Cq.x, Cq.w, t.a), t.b);
+    return r;
+}
+
 
 // bilinear RGB fetch from a bordered level (global memory or LDS pointer)
 template <bool EXACT>
@@ -131,6 +176,21 @@ __device__ __forceinline__ float4 cube_fetch_rgba(const float4* __restrict__ lvl
     r.y = lerp_fma(lerp_fma(t00.y, t10.y, t.a), lerp_fma(t01.y, t11.y, t.a), t.b);
     r.z = lerp_fma(lerp_fma(t00.z, t10.z, t.a), lerp_fma(t01.z, t11.z, t.a), t.b);
     r.w = lerp_fma(lerp_fma(t00.w, t10.w, t.a), lerp_fma(t01.w, t11.w, t.a), t.b);
+    return r;
+}
+
+// bilinear RGB fetch from the "cells" twin of a level: cell (face, j0, i0), i0/j0 in [0, n] (bordered tap
+// coordinates), holds the 2x2 RGB footprint {t00, t10, t01, t11} in 48 contiguous bytes -> 3 loads.
+template <bool EXACT>
+__device__ __forceinline__ f3 cube_fetch_rgb_cells(const float4* __restrict__ cells, int n, f3 d) {
+    CubeTap t = cube_tap<EXACT>(d, n);
+    int nc = n + 1;
+    const float4* c = cells + (size_t)((t.face * nc + t.j0) * nc + t.i0) * 3;
+    float4 A = c[0], Bq = c[1], Cq = c[2];
+    f3 r;
+    r.x = lerp_fma(lerp_fma(A.x, A.w, t.a), lerp_fma(Bq.z, Cq.y, t.a), t.b);
+    r.y = lerp_fma(lerp_fma(A.y, Bq.x, t.a), lerp_fma(Bq.w, Cq.z, t.a), t.b);
+    r.z = lerp_fma(lerp_fma(A.z, Bq.y, t.a), lerp_fma(Cq.x, Cq.w, t.a), t.b);
     return r;
 }
 

@@ -84,7 +84,8 @@ class PbrkShadeArgs(C.Structure):
                 ("base_color", C.c_void_p), ("normal", C.c_void_p), ("orm", C.c_void_p), ("emissive", C.c_void_p),
                 ("depth", C.c_void_p), ("irradiance_bordered", C.c_void_p), ("irradiance_size", C.c_int),
                 ("prefiltered_bordered", C.c_void_p), ("prefiltered_size", C.c_int), ("prefiltered_levels", C.c_int),
-                ("lut", C.c_void_p), ("lut_size", C.c_int), ("out", C.c_void_p), ("out_format", C.c_int), ("flags", C.c_int),
+                ("lut", C.c_void_p), ("lut_size", C.c_int), ("irradiance_cells", C.c_void_p), ("prefiltered_cells", C.c_void_p),
+                ("prefiltered_cells_first", C.c_int), ("lut_cells", C.c_void_p), ("out", C.c_void_p), ("out_format", C.c_int), ("flags", C.c_int),
                 ("globals", C.c_float * 138)]
 
 
@@ -169,6 +170,7 @@ PROTOTYPES = {
     "pbrk_cells_bytes": (C.c_size_t, [C.c_int]), "pbrk_cells_build": (C.c_int, [VP, C.c_int, VP, VP]),
     "pbrk_shade": (C.c_int, [C.POINTER(PbrkShadeArgs), VP]),
     "pbrk_mc_stats": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "pbrk_lut_cells_build": (C.c_int, [VP, C.c_int, VP, VP]),
 }
 
 _LIB = None
