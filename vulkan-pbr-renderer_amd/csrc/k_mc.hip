@@ -149,6 +149,149 @@ __global__ __launch_bounds__(256) void k_mc_filter(const McArgs p) {
     }
 }
 
+__device__ __forceinline__ void cube_project(f3 L, float nf, float off, int* face, float* u, float* v) {
+    float fid = __builtin_amdgcn_cubeid(L.x, L.y, L.z);
+    float sc = __builtin_amdgcn_cubesc(L.x, L.y, L.z);
+    float tc = __builtin_amdgcn_cubetc(L.x, L.y, L.z);
+    float ma2 = __builtin_amdgcn_cubema(L.x, L.y, L.z);
+    float h = __builtin_amdgcn_rcpf(fabsf(ma2)) * nf;
+    *u = fmaf(sc, h, off);
+    *v = fmaf(tc, h, off);
+    *face = (int)fid;
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-resident variant: when the whole bordered source level fits in LDS (n_src <= 32: 111 KB of the CU's
+// 160 KB), one 1024-thread workgroup per CU copies it in once and serves every tap with ds_read_b128
+// (256 B/clk/CU) instead of vector-memory instructions (16 clk each): the kernel becomes VALU-bound.
+// ------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(1024) void k_mc_filter_lds(const McArgs p) {
+    constexpr int BLOCK = 1024;
+    constexpr int TX = BLOCK / S;
+    constexpr int TW = TX >= 32 ? 32 : TX;
+    constexpr int TH = TX / TW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_l[];
+    float4* lvl = (float4*)smem_l;
+    const int nb = p.n_src + 2;
+    const int n_texels = 6 * nb * nb;
+    float* red = (float*)(lvl + n_texels);
+
+    for (int i = threadIdx.x; i < n_texels; i += BLOCK) lvl[i] = p.src[i];
+
+    unsigned tile = blockIdx.x;
+    int face = p.face0 + (int)(tile / (unsigned)p.tiles_per_face);
+    int tf = (int)(tile % (unsigned)p.tiles_per_face);
+    int ty = tf / p.tiles_x, tx = tf % p.tiles_x;
+    int t = threadIdx.x % TX;
+    int s = threadIdx.x / TX;
+    if (TX >= 64) s = __builtin_amdgcn_readfirstlane(s);
+    int x = tx * TW + (t % TW);
+    int y = p.y0 + ty * TH + (t / TW);
+    bool valid = (x < p.size) && (y < p.y0 + p.rows);
+    int xc = min(x, p.size - 1), yc = min(y, p.y0 + p.rows - 1);
+
+    f3 R = face_texel_dir(face, xc, yc, p.size);
+    f3 T = tangent_of(R);
+    f3 B = cross3(T, R);
+    const float nf = (float)p.n_src;
+    const float off = 0.5f * nf + 0.5f;
+    const float4* __restrict__ tab = p.tab;
+    __syncthreads();
+
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    auto one_sample = [&](float ex, float ey, float ez, float ew) {
+        f3 L;
+        L.x = fmaf(ex, B.x, fmaf(ey, T.x, ez * R.x));
+        L.y = fmaf(ex, B.y, fmaf(ey, T.y, ez * R.y));
+        L.z = fmaf(ex, B.z, fmaf(ey, T.z, ez * R.z));
+        int f; float u, v;
+        cube_project(L, nf, off, &f, &u, &v);
+        float a = __builtin_amdgcn_fractf(u), b = __builtin_amdgcn_fractf(v);
+        int i0 = min((int)u, p.n_src), j0 = min((int)v, p.n_src);          // LDS reads are not range-checked: keep taps in the level
+        const float4* wp = lvl + ((min(f, 5) * nb + j0) * nb + i0);
+        float4 q00 = wp[0], q10 = wp[1], q01 = wp[nb], q11 = wp[nb + 1];
+        float cr = lerp_fma(lerp_fma(q00.x, q10.x, a), lerp_fma(q01.x, q11.x, a), b);
+        float cg = lerp_fma(lerp_fma(q00.y, q10.y, a), lerp_fma(q01.y, q11.y, a), b);
+        float cb = lerp_fma(lerp_fma(q00.z, q10.z, a), lerp_fma(q01.z, q11.z, a), b);
+        ar = fmaf(ew, cr, ar);
+        ag = fmaf(ew, cg, ag);
+        ab = fmaf(ew, cb, ab);
+    };
+#pragma unroll 4
+    for (int i = s; i < p.n_tab; i += S) {
+        float4 e = tab[i];
+        one_sample(e.x, e.y, e.z, e.w);
+    }
+
+    if (S > 1) {
+        red[(s * TX + t) * 3 + 0] = ar;
+        red[(s * TX + t) * 3 + 1] = ag;
+        red[(s * TX + t) * 3 + 2] = ab;
+        __syncthreads();
+        for (int stride = S / 2; stride >= 1; stride >>= 1) {
+            if (s < stride) {
+                int a2 = (s * TX + t) * 3, b2 = ((s + stride) * TX + t) * 3;
+                red[a2 + 0] += red[b2 + 0];
+                red[a2 + 1] += red[b2 + 1];
+                red[a2 + 2] += red[b2 + 2];
+            }
+            __syncthreads();
+        }
+        ar = red[t * 3 + 0]; ag = red[t * 3 + 1]; ab = red[t * 3 + 2];
+    }
+    if (valid && s == 0) {
+        float4 o;
+        o.x = ar / p.divisor; o.y = ag / p.divisor; o.z = ab / p.divisor; o.w = p.alpha;
+        p.out[((size_t)face * p.size + y) * p.size + x] = o;
+    }
+}
+
+template <int S>
+static void launch_mc_lds_s(McArgs a, int nfaces, size_t lds, hipStream_t st) {
+    constexpr int TX = 1024 / S;
+    constexpr int TW = TX >= 32 ? 32 : TX;
+    constexpr int TH = TX / TW;
+    a.tiles_x = (a.size + TW - 1) / TW;
+    int tiles_y = (a.rows + TH - 1) / TH;
+    a.tiles_per_face = a.tiles_x * tiles_y;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_mc_filter_lds<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(k_mc_filter_lds<S>, dim3((unsigned)(a.tiles_per_face * nfaces)), dim3(1024), lds, st, a);
+}
+
+// returns false when the level does not fit in LDS
+static bool launch_mc_lds(McArgs a, int nfaces, hipStream_t st) {
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("PBR_MC_LDS"); mode = e ? atoi(e) : 1; }
+    int nb = a.n_src + 2;
+    size_t lvl_bytes = (size_t)6 * nb * nb * 16;
+    if (!mode || lvl_bytes > 112 * 1024) return false;
+    // Measured (C4 / C2 on MI355X): with a 111 KB level only one 1024-thread workgroup fits per CU (16 waves) and the
+    // VALU-bound loop runs at ~4.4 clk/instruction; the direct kernel (32 waves/CU, 3 loads/sample) then wins on big
+    // outputs.  Small levels (several workgroups per CU) and small outputs (launch-limited) win with LDS.
+    if (lvl_bytes > 48 * 1024 && (size_t)6 * a.size * a.size > ((size_t)1 << 19)) return false;
+    // S from the level size only (deterministic under sharding): at least 512 workgroups of 1024 threads
+    size_t texels = (size_t)6 * a.size * a.size;
+    int S = 1;
+    while (S < 1024 && texels * (size_t)S < (size_t)512 * 1024) S <<= 1;
+    size_t lds = lvl_bytes + (S > 1 ? (size_t)1024 * 3 * 4 : 0);
+    switch (S) {
+    case 1: launch_mc_lds_s<1>(a, nfaces, lds, st); break;
+    case 2: launch_mc_lds_s<2>(a, nfaces, lds, st); break;
+    case 4: launch_mc_lds_s<4>(a, nfaces, lds, st); break;
+    case 8: launch_mc_lds_s<8>(a, nfaces, lds, st); break;
+    case 16: launch_mc_lds_s<16>(a, nfaces, lds, st); break;
+    case 32: launch_mc_lds_s<32>(a, nfaces, lds, st); break;
+    case 64: launch_mc_lds_s<64>(a, nfaces, lds, st); break;
+    case 128: launch_mc_lds_s<128>(a, nfaces, lds, st); break;
+    case 256: launch_mc_lds_s<256>(a, nfaces, lds, st); break;
+    case 512: launch_mc_lds_s<512>(a, nfaces, lds, st); break;
+    default: launch_mc_lds_s<1024>(a, nfaces, lds, st); break;
+    }
+    return true;
+}
+
 // ==========================================================================================
 // Binned variant for large output levels (one 16x16 output tile per workgroup, S = 1).
 //
@@ -180,16 +323,6 @@ struct BinArgs {
     unsigned long long* stats;   // optional: [0] += wave-samples served by the fallback path, [1] += all wave-samples
 };
 
-__device__ __forceinline__ void cube_project(f3 L, float nf, float off, int* face, float* u, float* v) {
-    float fid = __builtin_amdgcn_cubeid(L.x, L.y, L.z);
-    float sc = __builtin_amdgcn_cubesc(L.x, L.y, L.z);
-    float tc = __builtin_amdgcn_cubetc(L.x, L.y, L.z);
-    float ma2 = __builtin_amdgcn_cubema(L.x, L.y, L.z);
-    float h = __builtin_amdgcn_rcpf(fabsf(ma2)) * nf;
-    *u = fmaf(sc, h, off);
-    *v = fmaf(tc, h, off);
-    *face = (int)fid;
-}
 
 __device__ __forceinline__ void taps_lds(const float4* __restrict__ win, int WS, int lx, int ly, f3& t00, f3& t10, f3& t01, f3& t11) {
     const float4* wp = win + (ly * WS + lx);
@@ -475,6 +608,7 @@ extern "C" int pbrk_mc_filter(const void* src_bordered_level, const void* src_ce
     hipStream_t st = (hipStream_t)stream;
     // Kernel choice and the sample-split factor S depend on the LEVEL size only
     if (launch_binned(a, nfaces, st)) return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+    if (launch_mc_lds(a, nfaces, st)) return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
     // Sample-split factor S depends on the LEVEL size only (not on the dispatched sub-range), so that a
     // sharded dispatch sums in exactly the same order as a full one (bit-identical results).
     size_t texels = (size_t)6 * out_size * out_size;
