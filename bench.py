@@ -142,10 +142,17 @@ def main():
     import torch
     import torch.distributed as dist
     import pbrhip
-    torch.cuda.set_device(local_rank)
+    # PBR_BENCH_BACKEND=gloo is a functional rehearsal of the N>1 path on a box with fewer GPUs than ranks (tiles are
+    # staged through host memory; timings are meaningless); the real path is RCCL ("nccl") with one GPU per rank.
+    backend = os.environ.get("PBR_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    L = pbrhip.init(device=local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
+    L = pbrhip.init(device=dev_index)
     L.GPUX_EnableOpTiming(1)
 
     # ---- resources: env cube (level 0 resident), output maps over torch-owned HBM (so RCCL can move them)
@@ -193,17 +200,24 @@ def main():
         L.GPU_GraphWait(graph)
         L.GPU_ResetDescriptorArena(arena)
         if world > 1:                                                             # one grouped RCCL exchange: tiles -> rank 0
-            ops = []
+            ops, staged = [], []
             if rank == 0:
                 for r in range(1, world):
                     for u in all_units[r]:
-                        ops.append(dist.P2POp(dist.irecv, unit_slice(*u), r))
+                        dst = unit_slice(*u)
+                        buf = dst if backend == "nccl" else torch.empty(dst.shape, dtype=dst.dtype)
+                        staged.append((dst, buf))
+                        ops.append(dist.P2POp(dist.irecv, buf, r))
             else:
                 for u in all_units[rank]:
-                    ops.append(dist.P2POp(dist.isend, unit_slice(*u), 0))
+                    src = unit_slice(*u)
+                    ops.append(dist.P2POp(dist.isend, src if backend == "nccl" else src.cpu(), 0))
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
+            if backend != "nccl":
+                for dst, buf in staged:
+                    dst.copy_(buf)
 
     def sync():
         if world > 1:
@@ -224,7 +238,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -308,6 +322,12 @@ def main():
                 err = np.abs(got[f, y].astype(np.float64) - want) / np.maximum(np.abs(want), 1e-3)
                 worst = max(worst, float(err.max()))
         extra["check_max_rel_err_vs_oracle"] = worst
+        if world > 1:      # the gathered result must equal what one GPU computes alone, bit for bit
+            gathered = spec_mem.clone()
+            one, n_one = pbrhip.partition(spec_size, 1, irr_size, W, 1, 0)
+            L.PBR_RecordUnits(pipes, graph, arena, env_tex, C.byref(maps), one, n_one)
+            L.GPU_GraphSubmit(graph); L.GPU_GraphWait(graph); L.GPU_ResetDescriptorArena(arena)
+            extra["check_gather_equals_single_gpu"] = bool(torch.equal(gathered, spec_mem))
 
     if rank == 0:
         out = {
