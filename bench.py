@@ -278,18 +278,45 @@ def main():
         kernels.append(ent)
     kernels.sort(key=lambda e: -e["avg_ms"] * e["launches_per_step"])
 
+    # HBM traffic per launch from the committed rocprofv3 PMC summary of this same command (profiles/, separate
+    # --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction, WRITE_SIZE exact)
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", f"r01_{args.workload}_pmc.json")) as f:
+            pmc = json.load(f).get("kernels", {})
+    except Exception:
+        pass
+
+    def traffic_for(kernel_prefix, grid_threads):
+        for name, e in pmc.items():
+            if name.startswith(kernel_prefix) and name.endswith(f"grid={grid_threads}"):
+                if "fetch_bytes_corrected_max" in e and "write_bytes_max" in e:
+                    return e["fetch_bytes_corrected_max"] + e["write_bytes_max"]
+        return None
+
+    for ent in kernels:
+        nm = ent["kernel"]
+        if nm.startswith("K4b.prefilter_mc.mip") and world == 1:
+            size = max(1, spec_size >> int(nm.rsplit("mip", 1)[1]))
+            if size >= 512:
+                ent["traffic"] = traffic_for("void k_mc_filter<1, 4, true>", 6 * size * size)
+        elif nm.startswith("K4a.") and world == 1:
+            ent["traffic"] = traffic_for("k_prefilter_copy", 256 * 64 * 256)
+        elif nm == "K2.mip_chain" and world == 1:
+            ent["traffic"] = None
+
     roofline = None
     if world == 1 and kernels:
         dom = next((k for k in kernels if "frac" in k), None)
         if dom is not None:
             if dom["bound"] == "valu":
                 roofline = {"kernel": dom["kernel"], "bound": "valu", "achieved": dom["achieved_tflops"], "peak": PEAK_FP32_TFLOPS,
-                            "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None,
+                            "unit": "TFLOP/s", "frac": dom["frac"], "traffic": dom.get("traffic"),
                             "note": "Monte-Carlo mips are fp32-VALU bound (SURVEY S9): 65 algorithmic flop per non-zero-weight sample; "
                                     "the HBM-shaped kernels are listed under roofline_hbm"}
             else:
                 roofline = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["achieved_gbs"], "peak": PEAK_HBM_GBS,
-                            "unit": "GB/s", "frac": dom["frac"], "traffic": None}
+                            "unit": "GB/s", "frac": dom["frac"], "traffic": dom.get("traffic")}
     roofline_hbm = [{"kernel": k["kernel"], "bound": "hbm", "achieved": k["achieved_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": k["frac"], "avg_ms": k["avg_ms"]} for k in kernels if k.get("bound") == "hbm"]
 

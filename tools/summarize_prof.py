@@ -21,7 +21,8 @@ def main():
             agg = collections.defaultdict(list)
             for r in csv.DictReader(open(find(d, "_counter_collection.csv"))):
                 if r["Counter_Name"] == counter:
-                    agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+                    # one entry per (kernel, grid size): the same kernel serves several output levels
+                    agg[r["Kernel_Name"].split("(")[0] + " grid=" + r["Grid_Size"]].append(float(r["Counter_Value"]))
             for k, v in agg.items():
                 e = res["kernels"].setdefault(k, {})
                 e[counter + "_KiB_mean"] = sum(v) / len(v)
