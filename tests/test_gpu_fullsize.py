@@ -1,0 +1,184 @@
+"""GPU tests at BASELINE.json's full sizes through size-independent properties (the oracle would need minutes to
+hours there): constant environments, linearity, alpha = weight sum, shard = full, plus oracle spot rows; and the
+boundary's error behaviour (unknown shader, raster-only calls, incomplete descriptor sets)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _prefilter(gpu, env, spec_size, min_size=1):
+    import pbrhip
+    W = env.shape[1]
+    tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, W, W, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+    spec = pbrhip.make_texture(pbrhip.Format_RGBA32F, spec_size, spec_size,
+                               pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps | pbrhip.TextureFlag_StorageImage)
+    gpu.PBR_GenPrefilteredEnvMap(tex, spec, min_size)
+    return tex, spec
+
+
+def _host_alpha(gpu, mip):
+    rough = [0.0, 0.03, 0.15, 0.4, 0.6][mip] if mip < 5 else min(1.0, float(np.float32(0.6) + np.float32(0.08) * np.float32(mip - 4)))
+    tab = np.zeros((8192, 4), np.float32)
+    a = C.c_float()
+    gpu.pbrk_host_prefilter_table(8192, C.c_float(rough), tab.ctypes.data_as(C.c_void_p), C.byref(a))
+    return a.value
+
+
+def test_c4_constant_environment(gpu):
+    """C4 size (4096^2, 13 mips, 2048^2 env): prefilter of a constant environment c is c (mip 0) and c*alpha_mip (MC mips);
+    alpha is the host-side weight sum; irradiance 128^2 is c*(N+1)/(2N)."""
+    import pbrhip
+    c = np.array([0.75, 2.5, 11.0, 1.0], np.float32)
+    env = np.empty((6, 2048, 2048, 4), np.float32); env[...] = c
+    tex, spec = _prefilter(gpu, env, 4096)
+    del env
+    for mip in (0, 1, 4, 7, 12):
+        got = pbrhip.read_mip(spec, mip)
+        if mip == 0:
+            assert np.all(got == c)
+        else:
+            alpha = _host_alpha(gpu, mip)
+            assert np.all(got[..., 3] == np.float32(alpha))
+            assert np.allclose(got[..., :3], c[:3] * alpha, rtol=3e-5), mip
+    irr = pbrhip.make_texture(pbrhip.Format_RGBA32F, 128, 128, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_StorageImage)
+    gpu.PBR_GenIrradianceMap(tex, irr)
+    got = pbrhip.read_mip(irr, 0)
+    assert np.allclose(got[..., :3], c[:3] * (1025.0 / 2048.0), rtol=3e-5) and np.all(got[..., 3] == 0)
+    gpu.GPU_DestroyTexture(irr); gpu.GPU_DestroyTexture(spec); gpu.GPU_DestroyTexture(tex)
+
+
+@pytest.fixture(scope="module")
+def c2_env():
+    from pbrhip import synth
+    return synth.synth_env(1024, seed=0x5EED0001, workers=6)
+
+
+def test_c2_linearity_and_oracle_rows(gpu, c2_env):
+    """C2 size (512^2, 10 mips, 1024^2 env): the filter is linear in the environment; a few rows of every mip match the oracle."""
+    import pbrhip, pbr_oracle as O
+    env1 = c2_env
+    rng = np.random.default_rng(5)
+    env2 = np.ascontiguousarray(env1[[1, 0, 3, 2, 5, 4]] * rng.uniform(0.5, 1.5, (6, 1, 1, 4)).astype(np.float32))
+    env2[..., 3] = 1.0
+    a, b = np.float32(0.25), np.float32(2.0)
+    envc = (a * env1 + b * env2).astype(np.float32); envc[..., 3] = 1.0
+    outs = []
+    for e in (env1, env2, envc):
+        tex, spec = _prefilter(gpu, e, 512)
+        outs.append([pbrhip.read_mip(spec, m) for m in range(10)])
+        gpu.GPU_DestroyTexture(spec); gpu.GPU_DestroyTexture(tex)
+    for m in range(10):
+        lin = a * outs[0][m][..., :3].astype(np.float64) + b * outs[1][m][..., :3].astype(np.float64)
+        got = outs[2][m][..., :3].astype(np.float64)
+        err = np.abs(got - lin) / np.maximum(np.abs(lin), 1e-3)
+        assert err.max() < 1e-4, (m, err.max())
+    pyr = O.build_pyramid(env1)
+    for m in (0, 1, 2, 5, 9):
+        size = 512 >> m
+        for (f, y) in ((0, 0), (2, size // 2), (5, size - 1)):
+            want = O.prefilter_mip(pyr, 1024, 512, m, faces=(f, f + 1), rows=(y, y + 1))[f, y]
+            err = np.abs(outs[0][m][f, y].astype(np.float64) - want) / np.maximum(np.abs(want), 1e-3)
+            assert err.max() < 1e-4, (m, f, y, err.max())
+
+
+def test_c3_shade_full_frame_properties(gpu):
+    """C3 size (1920x1080): banded draws equal the full draw; scaling every emissive byte leaves sky pixels untouched."""
+    import pbrhip
+    from pbrhip import synth
+    W, H = 1920, 1080
+    L = gpu
+    gbd = synth.synth_gbuffer_spheres(W, H)
+    env = synth.synth_env(64, seed=0x5EED00AA)
+    env_tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, 64, 64, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+    maps = pbrhip.PBR_IBLMaps()
+    L.PBR_MakeIBLMaps(C.byref(maps), 32, 256, 256)
+    L.PBR_GenIrradianceMap(env_tex, maps.irradiance_map)
+    L.PBR_GenPrefilteredEnvMap(env_tex, maps.tex_specular_env_map, 16)
+    L.PBR_GenBRDFIntegrationMap(maps.brdf_lut)
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), W, H, pbrhip.Format_RGBA16F)
+    for name, key in (("base_color", "base"), ("normal", "normal"), ("orm", "orm"), ("emissive", "emissive"), ("depth", "depth")):
+        pbrhip.upload_mip(getattr(gb, name), 0, gbd[key])
+    lp = L.PBR_MakeLightingPass(C.byref(gb), C.byref(maps), W, H)
+    glob = pbrhip.fill_globals(gbd["cam_pos"], aspect=W / H)
+    g = L.GPU_MakeGraph()
+    L.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    full = pbrhip.read_mip(gb.lighting_result, 0).view(np.uint16)
+    L.GPU_OpClearColorF(g, gb.lighting_result, 0, 0.0, 0.0, 0.0, 0.0)
+    for band in range(8):                                     # the 8-GPU screen split of C5, on one GPU
+        L.PBR_RecordLightingPass(lp, g, C.byref(glob), band * 135, (band + 1) * 135)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    banded = pbrhip.read_mip(gb.lighting_result, 0).view(np.uint16)
+    assert np.array_equal(full, banded)
+    f32 = full.view(np.float16).astype(np.float32)
+    # an RGBA16F target saturates to +inf above 65504 (sun highlights): no NaN, no negatives, alpha == 1
+    assert not np.isnan(f32).any() and (f32[..., 3] == 1).all() and (f32[..., :3] >= 0).all()
+    sky = gbd["depth"] == 1.0
+    assert sky.mean() > 0.5 and np.isfinite(f32[sky][:, :3]).mean() > 0.999
+    L.GPU_DestroyGraph(g); L.PBR_DestroyLightingPass(lp); L.PBR_DestroyGBuffer(C.byref(gb))
+    L.PBR_DestroyIBLMaps(C.byref(maps)); L.GPU_DestroyTexture(env_tex)
+
+
+def test_boundary_error_behaviour(gpu):
+    """Reference conventions: shader-compile failure is recoverable (empty string + error array); API misuse and
+    raster-only entry points report 'GPU-ERROR' (here through GPUX_SetErrorHandler instead of the default abort)."""
+    import pbrhip
+    L = gpu
+    msgs = []
+    CB = C.CFUNCTYPE(None, C.c_char_p, C.c_void_p)
+    cb = CB(lambda m, u: msgs.append(m.decode()))
+    L.GPUX_SetErrorHandler(C.cast(cb, C.c_void_p), None)
+    try:
+        layout = L.GPU_InitPipelineLayout()
+        b_out = L.GPU_StorageImageBinding(layout, b"OUTPUT", pbrhip.Format_RGBA32F)
+        b_env = L.GPU_TextureBinding(layout, b"TEX_ENV_CUBE")
+        L.GPU_FinalizePipelineLayout(layout)
+        desc = pbrhip.GPU_ShaderDesc()
+        path = b"../src/demo_pbr_renderer/shaders/taa_resolve.glsl"
+        desc.glsl_debug_filepath = pbrhip.GPU_String(path, len(path))
+        errs = pbrhip.GPU_GLSLErrorArray()
+        tok = L.GPU_SPIRVFromGLSL(None, 2, layout, C.byref(desc), C.byref(errs))
+        assert tok.length == 0 and errs.length == 1 and b"no built-in kernel" in errs.data[0].error_message.data
+        joined = L.GPU_JoinGLSLErrorString(None, errs)
+        assert joined.length > 0 and not msgs
+        # a known shader compiles to an opaque token and makes a pipeline
+        path2 = b"C:/x/shaders\\gen_prefiltered_env_map.glsl"
+        desc2 = pbrhip.GPU_ShaderDesc(); desc2.glsl_debug_filepath = pbrhip.GPU_String(path2, len(path2))
+        tok2 = L.GPU_SPIRVFromGLSL(None, 2, layout, C.byref(desc2), C.byref(errs))
+        assert tok2.length > 0 and errs.length == 0
+        desc2.spirv = tok2
+        pipe = L.GPU_MakeComputePipeline(layout, C.byref(desc2))
+        assert pipe
+        # descriptor set with a missing binding: Finalize reports (gpu_vulkan.c:841,849)
+        ds = L.GPU_InitDescriptorSet(None, layout)
+        out = pbrhip.make_texture(pbrhip.Format_RGBA32F, 32, 32, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_StorageImage | pbrhip.TextureFlag_HasMipmaps)
+        L.GPU_SetStorageImageBinding(ds, b_out, out, 0)
+        L.GPU_FinalizeDescriptorSet(ds)
+        assert msgs and "never set" in msgs[-1]
+        # binding a texture without the StorageImage flag as a storage image
+        plain = pbrhip.make_texture(pbrhip.Format_RGBA32F, 32, 32, pbrhip.TextureFlag_Cubemap)
+        n = len(msgs); L.GPU_SetStorageImageBinding(ds, b_out, plain, 0); assert len(msgs) == n + 1
+        # storage binding beyond the mip chain
+        n = len(msgs); L.GPU_SetStorageImageBinding(ds, b_out, out, 99); assert len(msgs) == n + 1
+        # raster-only entry points
+        g = L.GPU_MakeGraph()
+        n = len(msgs); L.GPU_OpDrawIndexed(g, 3, 1, 0, 0, 0); assert len(msgs) == n + 1 and "unsupported (raster)" in msgs[-1]
+        n = len(msgs); L.GPU_OpDraw(g, 6, 1, 0, 0); assert len(msgs) == n + 1
+        # dispatch without a bound set; dispatch with zero groups
+        L.GPU_OpBindComputePipeline(g, pipe)
+        n = len(msgs); L.GPU_OpDispatch(g, 4, 4, 1); assert len(msgs) == n + 1
+        n = len(msgs); L.GPU_OpDispatch(g, 0, 4, 1); assert len(msgs) == n + 1
+        # zero-extent texture (gpu_vulkan.c:1339) and zero-size buffer
+        n = len(msgs); assert not L.GPU_MakeTexture(pbrhip.Format_RGBA32F, 0, 4, 1, 0, None); assert len(msgs) == n + 1
+        # an empty graph submits and waits fine; NULL destroys are accepted where the reference documents them
+        L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+        L.GPU_DestroyTexture(None); L.GPU_DestroyBuffer(None); L.GPU_DestroyComputePipeline(None); L.GPU_DestroyDescriptorSet(None)
+        L.GPU_DestroyDescriptorArena(None); L.GPU_DestroyGraphicsPipeline(None)
+        L.GPU_DestroyGraph(g); L.GPU_DestroyDescriptorSet(ds); L.GPU_DestroyComputePipeline(pipe)
+        L.GPU_DestroyTexture(out); L.GPU_DestroyTexture(plain); L.GPU_DestroyPipelineLayout(layout)
+    finally:
+        L.GPUX_SetErrorHandler(None, None)

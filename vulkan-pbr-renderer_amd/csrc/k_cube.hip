@@ -10,21 +10,19 @@
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mip_level(const float4* __restrict__ src, float4* __restrict__ dst,
                                                    int ns, int nd, int nfaces) {
-    size_t total = (size_t)nfaces * nd * nd;
-    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
-        int x = (int)(id % nd);
-        size_t r = id / nd;
-        int y = (int)(r % nd);
-        int f = (int)(r / nd);
-        const float4* p = src + ((size_t)f * ns + 2 * y) * ns + 2 * x;
-        float4 a = p[0], b = p[1], c = p[ns], d = p[ns + 1];
-        float4 o;
-        o.x = (((a.x + b.x) + c.x) + d.x) * 0.25f;
-        o.y = (((a.y + b.y) + c.y) + d.y) * 0.25f;
-        o.z = (((a.z + b.z) + c.z) + d.z) * 0.25f;
-        o.w = (((a.w + b.w) + c.w) + d.w) * 0.25f;
-        dst[id] = o;
-    }
+    // grid: x = column blocks of 64 texels, y = row blocks of 4 rows, z = layer (no integer division per texel)
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int f = blockIdx.z;
+    if (x >= nd || y >= nd || f >= nfaces) return;
+    const float4* p = src + ((size_t)f * ns + 2 * y) * ns + 2 * x;
+    float4 a = p[0], b = p[1], c = p[ns], d = p[ns + 1];
+    float4 o;
+    o.x = (((a.x + b.x) + c.x) + d.x) * 0.25f;
+    o.y = (((a.y + b.y) + c.y) + d.y) * 0.25f;
+    o.z = (((a.z + b.z) + c.z) + d.z) * 0.25f;
+    o.w = (((a.w + b.w) + c.w) + d.w) * 0.25f;
+    dst[((size_t)f * nd + y) * nd + x] = o;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -57,32 +55,29 @@ __device__ __forceinline__ float4 edge_texel(const float4* __restrict__ lvl, int
 
 __global__ __launch_bounds__(256) void k_border_level(const float4* __restrict__ lvl, float4* __restrict__ out, int n) {
     int nb = n + 2;
-    size_t total = (size_t)6 * nb * nb;
-    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
-        int bi = (int)(id % nb);
-        size_t r = id / nb;
-        int bj = (int)(r % nb);
-        int f = (int)(r / nb);
-        int i = bi - 1, j = bj - 1;
-        bool oi = (i < 0) | (i >= n), oj = (j < 0) | (j >= n);
-        float4 v;
-        if (!oi && !oj) {
-            v = lvl[((size_t)f * n + j) * n + i];
-        } else if (oi != oj) {
-            v = edge_texel(lvl, n, f, i, j);
-        } else {
-            // cube corner: the missing texel is the mean of the three that exist
-            int ci = i < 0 ? 0 : n - 1, cj = j < 0 ? 0 : n - 1;
-            float4 a = lvl[((size_t)f * n + cj) * n + ci];
-            float4 b = edge_texel(lvl, n, f, i, cj);
-            float4 c = edge_texel(lvl, n, f, ci, j);
-            v.x = ((a.x + b.x) + c.x) / 3.0f;
-            v.y = ((a.y + b.y) + c.y) / 3.0f;
-            v.z = ((a.z + b.z) + c.z) / 3.0f;
-            v.w = ((a.w + b.w) + c.w) / 3.0f;
-        }
-        out[id] = v;
+    int bi = blockIdx.x * 64 + (threadIdx.x & 63);
+    int bj = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int f = blockIdx.z;
+    if (bi >= nb || bj >= nb) return;
+    int i = bi - 1, j = bj - 1;
+    bool oi = (i < 0) | (i >= n), oj = (j < 0) | (j >= n);
+    float4 v;
+    if (!oi && !oj) {
+        v = lvl[((size_t)f * n + j) * n + i];
+    } else if (oi != oj) {
+        v = edge_texel(lvl, n, f, i, j);
+    } else {
+        // cube corner: the missing texel is the mean of the three that exist
+        int ci = i < 0 ? 0 : n - 1, cj = j < 0 ? 0 : n - 1;
+        float4 a = lvl[((size_t)f * n + cj) * n + ci];
+        float4 b = edge_texel(lvl, n, f, i, cj);
+        float4 c = edge_texel(lvl, n, f, ci, j);
+        v.x = ((a.x + b.x) + c.x) / 3.0f;
+        v.y = ((a.y + b.y) + c.y) / 3.0f;
+        v.z = ((a.z + b.z) + c.z) / 3.0f;
+        v.w = ((a.w + b.w) + c.w) / 3.0f;
     }
+    out[((size_t)f * nb + bj) * nb + bi] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -90,17 +85,15 @@ __global__ __launch_bounds__(256) void k_border_level(const float4* __restrict__
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prefilter_copy(const float4* __restrict__ src, int n_src,
                                                         float4* __restrict__ out, int size,
-                                                        int face0, int nfaces, int y0, int rows) {
-    size_t total = (size_t)nfaces * rows * size;
-    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
-        int x = (int)(id % size);
-        size_t r = id / size;
-        int y = y0 + (int)(r % rows);
-        int f = face0 + (int)(r / rows);
-        f3 R = face_texel_dir(f, x, y, size);
-        float4 v = cube_fetch_rgba<true>(src, n_src, R);
-        out[((size_t)f * size + y) * size + x] = v;
-    }
+                                                        int face0, int y0, int rows) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int yr = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int f = face0 + blockIdx.z;
+    if (x >= size || yr >= rows) return;
+    int y = y0 + yr;
+    f3 R = face_texel_dir(f, x, y, size);
+    float4 v = cube_fetch_rgba<true>(src, n_src, R);
+    out[((size_t)f * size + y) * size + x] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -120,8 +113,7 @@ extern "C" int pbrk_mip_chain(void* pyramid, int W, int levels, void* stream) {
         int ns = lvl_size(W, l - 1), nd = lvl_size(W, l);
         const float4* src = base + pbrk_level_offset(W, l - 1);
         float4* dst = base + pbrk_level_offset(W, l);
-        size_t total = (size_t)6 * nd * nd;
-        hipLaunchKernelGGL(k_mip_level, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, src, dst, ns, nd, 6);
+        hipLaunchKernelGGL(k_mip_level, dim3((nd + 63) / 64, (nd + 3) / 4, 6), dim3(256), 0, (hipStream_t)stream, src, dst, ns, nd, 6);
     }
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
@@ -129,8 +121,7 @@ extern "C" int pbrk_mip_chain(void* pyramid, int W, int levels, void* stream) {
 extern "C" int pbrk_box_downsample(const void* src, int ns, void* dst, int nlayers, void* stream) {
     if (!src || !dst || ns < 2 || (ns & 1) || nlayers < 1) return PBRK_E_ARG;
     int nd = ns / 2;
-    size_t total = (size_t)nlayers * nd * nd;
-    hipLaunchKernelGGL(k_mip_level, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_mip_level, dim3((nd + 63) / 64, (nd + 3) / 4, nlayers), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)src, (float4*)dst, ns, nd, nlayers);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
@@ -141,8 +132,7 @@ extern "C" int pbrk_border_build(const void* pyramid, void* bordered, int W, int
         int n = lvl_size(W, l);
         const float4* src = (const float4*)pyramid + pbrk_level_offset(W, l);
         float4* dst = (float4*)bordered + pbrk_bordered_level_offset(W, l);
-        size_t total = (size_t)6 * (n + 2) * (n + 2);
-        hipLaunchKernelGGL(k_border_level, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+        hipLaunchKernelGGL(k_border_level, dim3((n + 2 + 63) / 64, (n + 2 + 3) / 4, 6), dim3(256), 0, (hipStream_t)stream, src, dst, n);
     }
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
@@ -151,8 +141,7 @@ extern "C" int pbrk_prefilter_copy(const void* src_bordered_level, int n_src, vo
                                    int face0, int face1, int y0, int y1, void* stream) {
     if (!src_bordered_level || !out || n_src < 1 || out_size < 1) return PBRK_E_ARG;
     if (face0 < 0 || face1 > 6 || face0 >= face1 || y0 < 0 || y1 > out_size || y0 >= y1) return PBRK_E_ARG;
-    size_t total = (size_t)(face1 - face0) * (y1 - y0) * out_size;
-    hipLaunchKernelGGL(k_prefilter_copy, dim3(grid_for(total, 256, 256 * 64)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)src_bordered_level, n_src, (float4*)out, out_size, face0, face1 - face0, y0, y1 - y0);
+    hipLaunchKernelGGL(k_prefilter_copy, dim3((out_size + 63) / 64, (y1 - y0 + 3) / 4, face1 - face0), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)src_bordered_level, n_src, (float4*)out, out_size, face0, y0, y1 - y0);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }

@@ -564,27 +564,23 @@ static void launch_mc(McArgs a, int nfaces, hipStream_t st) {
 // ---- cells build: bordered level -> 2x2-footprint cells ----
 __global__ __launch_bounds__(256) void k_cells_build(const float4* __restrict__ b, float4* __restrict__ cells, int n) {
     int nb = n + 2, nc = n + 1;
-    size_t total = (size_t)6 * nc * nc;
-    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
-        int i = (int)(id % nc);
-        size_t r = id / nc;
-        int j = (int)(r % nc), f = (int)(r / nc);
-        const float4* p = b + ((size_t)f * nb + j) * nb + i;
-        float4 t00 = p[0], t10 = p[1], t01 = p[nb], t11 = p[nb + 1];
-        float4* o = cells + id * 3;
-        o[0] = make_float4(t00.x, t00.y, t00.z, t10.x);
-        o[1] = make_float4(t10.y, t10.z, t01.x, t01.y);
-        o[2] = make_float4(t01.z, t11.x, t11.y, t11.z);
-    }
+    int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int f = blockIdx.z;
+    if (i >= nc || j >= nc) return;
+    const float4* p = b + ((size_t)f * nb + j) * nb + i;
+    float4 t00 = p[0], t10 = p[1], t01 = p[nb], t11 = p[nb + 1];
+    float4* o = cells + ((size_t)(f * nc + j) * nc + i) * 3;
+    o[0] = make_float4(t00.x, t00.y, t00.z, t10.x);
+    o[1] = make_float4(t10.y, t10.z, t01.x, t01.y);
+    o[2] = make_float4(t01.z, t11.x, t11.y, t11.z);
 }
 
 extern "C" size_t pbrk_cells_bytes(int n) { return (size_t)6 * (n + 1) * (n + 1) * 48; }
 
 extern "C" int pbrk_cells_build(const void* bordered_level, int n, void* cells, void* stream) {
     if (!bordered_level || !cells || n < 1) return PBRK_E_ARG;
-    size_t total = (size_t)6 * (n + 1) * (n + 1);
-    size_t g = (total + 255) / 256; if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(k_cells_build, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float4*)bordered_level, (float4*)cells, n);
+    hipLaunchKernelGGL(k_cells_build, dim3((n + 1 + 63) / 64, (n + 1 + 3) / 4, 6), dim3(256), 0, (hipStream_t)stream, (const float4*)bordered_level, (float4*)cells, n);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
 

@@ -125,9 +125,10 @@ __device__ __forceinline__ float2 lut_fetch(const __half2* __restrict__ lut, con
 }
 
 __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
-    int total = p.w * p.h;
-    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < total; id += gridDim.x * blockDim.x) {
-        int px = p.x0 + id % p.w, py = p.y0 + id / p.w;
+    {   // grid: x = 64-pixel column blocks, y = 4-row blocks (no integer division per pixel)
+        int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6);
+        if (lx >= p.w || ly >= p.h) return;
+        int px = p.x0 + lx, py = p.y0 + ly;
         size_t pi = (size_t)py * p.width + px;
         uchar4 bb = p.base[pi], nn = p.normal[pi], oo = p.orm[pi], ee = p.emissive[pi];
         float depth = p.depth[pi];
@@ -288,9 +289,6 @@ extern "C" int pbrk_shade(const PbrkShadeArgs* a, void* stream) {
     for (int i = 0; i < 16; ++i) { p.wfc[i] = a->globals[32 + i]; p.ssw[i] = a->globals[96 + i]; }
     for (int i = 0; i < 3; ++i) { p.sun[i] = a->globals[128 + i]; p.cam[i] = a->globals[132 + i]; }
     p.frame_idx_mod_59 = a->globals[135];
-    long total = (long)p.w * p.h;
-    int grid = (int)((total + 255) / 256);
-    if (grid > 256 * 32) grid = 256 * 32;
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_shade, dim3((p.w + 63) / 64, (p.h + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }

@@ -30,8 +30,10 @@ __device__ __forceinline__ f3 normalize3(f3 a) {
 // EXACT: CubemapSampleDirFromFaceUV (reference shaders/gen_prefiltered_env_map.glsl:11-66):
 // texel (ix,iy) of an n*n face -> unit direction through the texel centre.
 __device__ __forceinline__ f3 face_texel_dir(int face, int ix, int iy, int n) {
-    float u = __fdiv_rn((float)ix + 0.5f, (float)n);
-    float v = __fdiv_rn((float)iy + 0.5f, (float)n);
+    // power-of-two sizes (every size the reference and BASELINE use): x / n == x * (1/n) exactly
+    float u, v;
+    if ((n & (n - 1)) == 0) { float rn = 1.0f / (float)n; u = ((float)ix + 0.5f) * rn; v = ((float)iy + 0.5f) * rn; }
+    else { u = __fdiv_rn((float)ix + 0.5f, (float)n); v = __fdiv_rn((float)iy + 0.5f, (float)n); }
     float sc = 2 * (u - 0.5f);
     float tc = 2 * (v - 0.5f);
     f3 r;
