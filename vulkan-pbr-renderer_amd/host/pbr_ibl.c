@@ -257,16 +257,23 @@ uint32_t PBR_PartitionIBL(uint32_t specular_size, uint32_t min_size, uint32_t ir
         if (pass == 0) { cap_all = n; all = (PBR_WorkUnit*)malloc(sizeof(PBR_WorkUnit) * (cap_all ? cap_all : 1)); }
     }
     qsort(all, n, sizeof *all, cmp_cost_desc);
-    /* greedy longest-first onto the least loaded rank (ties -> lowest rank) */
+    /* Communication-aware greedy assignment.  Outputs are gathered on rank 0, so the copy mip (mip 0: 75 % of the
+     * output bytes, 0.4 % of the compute) stays on rank 0 and never crosses xGMI; its cost is charged to rank 0's
+     * load first.  Everything else: longest-first onto the least loaded rank (ties -> lowest rank). */
     double* load = (double*)calloc((size_t)world, sizeof(double));
     uint32_t written = 0;
-    for (uint32_t k = 0; k < n; ++k) {
-        int best = 0;
-        for (int r = 1; r < world; ++r) if (load[r] < load[best]) best = r;
-        load[best] += all[k].cost;
-        if (rank < 0 || best == rank) {
-            if (written < capacity && out) out[written] = all[k];
-            ++written;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (uint32_t k = 0; k < n; ++k) {
+            int pinned = all[k].kind == PBR_Unit_Prefilter && all[k].mip == 0;
+            if ((pass == 0) != pinned) continue;
+            int best = 0;
+            if (!pinned) for (int r = 1; r < world; ++r) if (load[r] < load[best]) best = r;
+            /* the copy mip is bandwidth work: charge it at its byte cost relative to a Monte-Carlo sample (~1 sample / 48 B) */
+            load[best] += pinned ? all[k].cost * 16.0 : all[k].cost;
+            if (rank < 0 || best == rank) {
+                if (written < capacity && out) out[written] = all[k];
+                ++written;
+            }
         }
     }
     free(load); free(all);
