@@ -55,6 +55,10 @@ GPU_API GPU_Texture* GPUX_MakeTextureExternal(GPU_Format format, uint32_t width,
 GPU_API uint64_t GPUX_TextureTotalBytes(const GPU_Texture* texture);
 GPU_API uint64_t GPUX_TextureMipOffset(const GPU_Texture* texture, uint32_t mip_level);
 
+/* ---- equirectangular input (extension; the reference only loads cube strips): uploads the RGBA32F panorama, converts it
+ * to a face_size^2 cubemap (K6) and generates the mip chain before returning, like GPU_MakeTexture(data != NULL). ---- */
+GPU_API GPU_Texture* GPUX_MakeCubemapFromEquirect(const void* rgba32f, uint32_t width, uint32_t height, uint32_t face_size, GPU_TextureFlags extra_flags);
+
 /* ---- per-op timing with HIP events on the graph's own stream ---- */
 GPU_API void GPUX_EnableOpTiming(int enable);
 GPU_API uint32_t GPUX_GraphTimedOpCount(GPU_Graph* graph);          /* ops of the last waited submission */

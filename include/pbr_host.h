@@ -24,6 +24,16 @@ float* PBR_DecodeHDR(const void* bytes, size_t size, int* w, int* h, const char*
 GPU_Texture* PBR_MakeTextureFromHDRIMemory(const void* bytes, size_t size);
 GPU_Texture* PBR_MakeTextureFromHDRIFile(const char* filepath);
 
+/* ---- extensions around the input/output files ----
+ * Equirectangular .hdr (2:1) -> cubemap with mips; the strip loader above stays the reference path. */
+GPU_Texture* PBR_MakeTextureFromEquirectHDRIMemory(const void* bytes, size_t size, uint32_t face_size);
+GPU_Texture* PBR_MakeTextureFromEquirectHDRIFile(const char* filepath, uint32_t face_size);
+/* Radiance RGBE writer (flat scanlines): returns malloc'ed file bytes, *out_size set. rgba: float [h][w][4] (alpha dropped). */
+void* PBR_EncodeHDR(const float* rgba, int w, int h, size_t* out_size);
+int   PBR_WriteHDRFile(const char* filepath, const float* rgba, int w, int h);
+/* One mip of a cubemap as a vertical-strip .hdr (the layout MakeTextureFromHDRIFile reads back). Returns 0 on success. */
+int   PBR_WriteCubeStripHDR(const char* filepath, GPU_Texture* cube, uint32_t mip_level);
+
 /* ---- IBL precompute, render.cpp:505-619 ---- */
 typedef struct PBR_IBLMaps {
     GPU_Texture* irradiance_map;        /* RGBA32F cube, render.cpp:794 (32x32) */

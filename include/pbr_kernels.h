@@ -71,6 +71,10 @@ int pbrk_box_downsample(const void* src, int ns, void* dst, int nlayers, void* s
  *      src/gpu/gpu_vulkan.c:613-634 applied to a cube view). */
 int pbrk_border_build(const void* pyramid, void* bordered, int W, int levels, void* stream);
 
+/* ---- K6 (extension): equirectangular RGBA32F panorama [h][w] -> cube level 0 [6][size][size].
+ * Z-up: u = atan2(y,x)/2pi + .5 (wraps), v = acos(z/|d|)/pi (clamps); bilinear; angles in fp64. */
+int pbrk_equirect_to_cube(const void* equirect_rgba32f, int w, int h, void* cube_level0, int size, void* stream);
+
 /* ---- K1: split-sum BRDF LUT (shaders/gen_brdf_integration_map.glsl:142-210).
  * angles4: device copy of pbrk_host_sample_angles(nsamples); view_cs: device float2[size] with
  * (cos, sin) of acos((x+.5)/size) computed on the host.  Rows [y0,y1) are written. */

@@ -405,6 +405,37 @@ void orc_cube_sample(const float* pyr, int W, int levels, const float dir[3], fl
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Extension (no reference counterpart: the reference only loads cube strips):    */
+/* equirectangular RGBA32F panorama -> cube level 0.  Z-up; u = atan2(y,x)/2pi + .5 (wraps),     */
+/* v = acos(z/|d|)/pi (clamps); bilinear with exact fp32 weights; the two angles in fp64.        */
+/* ------------------------------------------------------------------------------------------ */
+void orc_equirect_to_cube(const float* eq, int w, int h, int size, float* out) {
+    const double inv_2pi = 0.15915494309189535, inv_pi = 0.3183098861837907;
+    #pragma omp parallel for collapse(2) num_threads(ORC_NT())
+    for (int f = 0; f < 6; ++f)
+        for (int y = 0; y < size; ++y)
+            for (int x = 0; x < size; ++x) {
+                v3 d = face_dir(f, ((float)x + 0.5f) / (float)size, ((float)y + 0.5f) / (float)size);
+                double len = sqrt((double)d.x * d.x + (double)d.y * d.y + (double)d.z * d.z);
+                double cz = (double)d.z / len; if (cz > 1.0) cz = 1.0; if (cz < -1.0) cz = -1.0;
+                float u = (float)(atan2((double)d.y, (double)d.x) * inv_2pi + 0.5);
+                float v = (float)(acos(cz) * inv_pi);
+                float fx = u * (float)w - 0.5f, fy = v * (float)h - 0.5f;
+                float flx = floorf(fx), fly = floorf(fy);
+                float a = fx - flx, b = fy - fly;
+                int i0 = (int)flx, j0 = (int)fly, i1 = i0 + 1, j1 = j0 + 1;
+                i0 = ((i0 % w) + w) % w; i1 = ((i1 % w) + w) % w;
+                j0 = clampi(j0, 0, h - 1); j1 = clampi(j1, 0, h - 1);
+                float* o = out + (((size_t)f * size + y) * size + x) * 4;
+                for (int k = 0; k < 4; ++k) {
+                    float t00 = eq[((size_t)j0 * w + i0) * 4 + k], t10 = eq[((size_t)j0 * w + i1) * 4 + k];
+                    float t01 = eq[((size_t)j1 * w + i0) * 4 + k], t11 = eq[((size_t)j1 * w + i1) * 4 + k];
+                    o[k] = lerpf(lerpf(t00, t10, a), lerpf(t01, t11, a), b);
+                }
+            }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* A4: Fibonacci-spiral hemisphere sample angles.  gen_prefiltered_env_map.glsl:125-128 (same   */
 /* text gen_irradiance_map.glsl:85-88, gen_brdf_integration_map.glsl:171-174):                  */
 /*   x = float(i)/float(N); y = float(i)/GOLDEN_RATIO; pitch = PI - acos(x - 1.); yaw = 2.*PI*y  */

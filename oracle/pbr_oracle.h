@@ -67,6 +67,9 @@ int    orc_cube_neighbor(int face, int n, int i, int j, int* ni, int* nj);
 /* analytic environment of SURVEY 8c: (1+.5dx, 1+.5dy^2, 1+.5dz*dx, 1), d normalised */
 void   orc_env_analytic(const float dir[3], float out[4]);
 
+/* ---- extension (no reference counterpart): equirectangular RGBA32F [h][w][4] -> cube level 0 [6][size][size][4] ---- */
+void   orc_equirect_to_cube(const float* equirect, int w, int h, int size, float* out);
+
 /* ---- A4/A5: per-sample tables (Fibonacci hemisphere; Beckmann weights) ---- */
 /* cs[i*4+0..3] = cos(pitch_i), sin(pitch_i), cos(yaw_i), sin(yaw_i)  (gen_prefiltered_env_map.glsl:125-128) */
 void   orc_sample_angles(int nsamples, float* cs);

@@ -91,6 +91,7 @@ def lib():
     L.orc_f32_to_f16.restype = C.c_uint16
     L.orc_f16_to_f32.argtypes = [C.c_uint16]
     L.orc_f16_to_f32.restype = C.c_float
+    L.orc_equirect_to_cube.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p]
     L.orc_shade.argtypes = [C.POINTER(OrcGlobals), C.POINTER(OrcShadeInputs), C.c_int,
                             C.c_int, C.c_int, C.c_int, C.c_int, f32p]
     _LIB = L
@@ -173,6 +174,14 @@ def rgbe_decode(data: bytes):
     rc = lib().orc_rgbe_decode(data, len(data), C.byref(w), C.byref(h), out.ctypes.data_as(C.c_void_p))
     if rc:
         raise ValueError(f"rgbe decode failed: {rc}")
+    return out
+
+
+def equirect_to_cube(eq, size):
+    eq = np.ascontiguousarray(eq, dtype=np.float32)
+    h, w, _ = eq.shape
+    out = np.zeros((6, size, size, 4), dtype=np.float32)
+    lib().orc_equirect_to_cube(eq.reshape(-1), w, h, size, out.reshape(-1))
     return out
 
 

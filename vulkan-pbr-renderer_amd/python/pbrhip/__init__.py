@@ -139,11 +139,15 @@ PROTOTYPES = {
     "GPUX_TextureMipBytes": (C.c_uint64, [TexP, U32]), "GPUX_TextureDevicePtr": (VP, [TexP, U32]), "GPUX_BufferDevicePtr": (VP, [BufP]),
     "GPUX_MakeTextureExternal": (TexP, [C.c_int, U32, U32, U32, C.c_int, VP, C.c_uint64]),
     "GPUX_TextureTotalBytes": (C.c_uint64, [TexP]), "GPUX_TextureMipOffset": (C.c_uint64, [TexP, U32]),
+    "GPUX_MakeCubemapFromEquirect": (TexP, [VP, U32, U32, U32, C.c_int]),
     "GPUX_GraphStream": (VP, [VP]), "GPUX_EnableOpTiming": (None, [C.c_int]), "GPUX_GraphTimedOpCount": (U32, [VP]),
     "GPUX_GraphTimedOpName": (C.c_char_p, [VP, U32]), "GPUX_GraphTimedOpMs": (C.c_float, [VP, U32]),
     # --- host layer (include/pbr_host.h) ---
     "PBR_DecodeHDR": (VP, [VP, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
     "PBR_MakeTextureFromHDRIMemory": (TexP, [VP, C.c_size_t]), "PBR_MakeTextureFromHDRIFile": (TexP, [C.c_char_p]),
+    "PBR_MakeTextureFromEquirectHDRIMemory": (TexP, [VP, C.c_size_t, U32]), "PBR_MakeTextureFromEquirectHDRIFile": (TexP, [C.c_char_p, U32]),
+    "PBR_EncodeHDR": (VP, [VP, C.c_int, C.c_int, C.POINTER(C.c_size_t)]), "PBR_WriteHDRFile": (C.c_int, [C.c_char_p, VP, C.c_int, C.c_int]),
+    "PBR_WriteCubeStripHDR": (C.c_int, [C.c_char_p, TexP, U32]),
     "PBR_MakeIBLMaps": (None, [C.POINTER(PBR_IBLMaps), U32, U32, U32]), "PBR_DestroyIBLMaps": (None, [C.POINTER(PBR_IBLMaps)]),
     "PBR_GenIrradianceMap": (None, [TexP, TexP]), "PBR_GenPrefilteredEnvMap": (None, [TexP, TexP, U32]),
     "PBR_GenBRDFIntegrationMap": (None, [TexP]),
@@ -171,6 +175,7 @@ PROTOTYPES = {
     "pbrk_shade": (C.c_int, [C.POINTER(PbrkShadeArgs), VP]),
     "pbrk_mc_stats": (C.c_int, [C.POINTER(C.c_uint64)]),
     "pbrk_lut_cells_build": (C.c_int, [VP, C.c_int, VP, VP]),
+    "pbrk_equirect_to_cube": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, VP]),
 }
 
 _LIB = None
