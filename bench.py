@@ -328,6 +328,10 @@ def main():
             extra["shade"] = shade_bench(L, pbrhip, maps, world)
         except Exception as e:      # the headline number must not depend on the extra
             extra["shade_error"] = repr(e)
+        try:
+            extra["lightgrid_sweep"] = sweep_bench(L, pbrhip)
+        except Exception as e:
+            extra["lightgrid_sweep_error"] = repr(e)
 
     if os.environ.get("PBR_MC_STATS") == "1":
         st = (C.c_uint64 * 2)()
@@ -412,6 +416,39 @@ def shade_bench(L, pbrhip, maps, world, frames=20):
            "roofline": {"kernel": "K5.shade", "bound": "hbm", "achieved": byt / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": byt / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}}
     L.GPU_DestroyGraph(g); L.PBR_DestroyLightingPass(lp); L.PBR_DestroyGBuffer(C.byref(gb))
+    return res
+
+
+def sweep_bench(L, pbrhip, frames=30):
+    """N2: 128^3 RGBA16F light grid, the per-frame sweep of render.cpp:1061-1072 (K7), directions cycling y, z, x."""
+    from pbrhip import synth
+    n = 128
+    scene = synth.synth_lightgrid(n, lit=False).view(np.uint16)
+    lg = L.PBR_MakeLightgrid(n)
+    tex = L.PBR_LightgridTexture(lg)
+    pbrhip.upload_mip(tex, 0, scene)
+    g = L.GPU_MakeGraph()
+    for _ in range(3):
+        L.PBR_RecordLightgridSweep(lg, g)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)                      # warm-up
+    for _ in range(frames):
+        L.PBR_RecordLightgridSweep(lg, g)
+    t0 = time.perf_counter()
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    wall = time.perf_counter() - t0
+    per_dir = {}
+    for i in range(L.GPUX_GraphTimedOpCount(g)):
+        per_dir.setdefault(L.GPUX_GraphTimedOpName(g, i).decode(), []).append(L.GPUX_GraphTimedOpMs(g, i))
+    empty = float((scene[..., 3].view(np.float16) < 0.5).mean())
+    byt = n ** 3 * 8.0 * (1.0 + empty)                            # 8 B read per voxel + 8 B written per empty voxel
+    k_ms = float(np.mean([v for vs in per_dir.values() for v in vs]))
+    res = {"workload": "N2: 128^3 RGBA16F light-grid sweep, one direction per frame", "frames": frames,
+           "kernel_avg_ms": k_ms, "kernel_avg_ms_by_direction": {k: float(np.mean(v)) for k, v in sorted(per_dir.items())},
+           "mvoxels_per_s_kernel": n ** 3 / (k_ms * 1e-3) / 1e6, "mvoxels_per_s_wall": n ** 3 * frames / wall / 1e6,
+           "empty_voxel_fraction": empty,
+           "roofline": {"kernel": "K7.sweep", "bound": "hbm", "achieved": byt / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": byt / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}}
+    L.GPU_DestroyGraph(g); L.PBR_DestroyLightgrid(lg)
     return res
 
 

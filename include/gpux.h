@@ -33,6 +33,9 @@ typedef struct GPUX_IBLConstants {
 /* ---- sub-range dispatch: like GPU_OpDispatch over the bound OUTPUT image, restricted to faces
  * [face0,face1) and rows [row0,row1) (rows of the LUT for gen_brdf_integration_map). ---- */
 GPU_API void GPUX_OpDispatchRows(GPU_Graph* graph, uint32_t face0, uint32_t face1, uint32_t row0, uint32_t row1);
+/* the same for the light-grid sweep pipeline (lightgrid_sweep.glsl): invocations (iy, iz) in [y0,y1) x [z0,z1),
+ * where GPU_OpDispatch(1, gy, gz) covers [0, 8 gy) x [0, 8 gz); the direction comes from the push constant. */
+GPU_API void GPUX_OpDispatchLines(GPU_Graph* graph, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1);
 
 /* ---- shade pass controls ---- */
 enum { GPUX_Shade_IBL = 1 << 0, GPUX_Shade_LightShafts = 1 << 1 };

@@ -109,6 +109,19 @@ GPU_GraphicsPipeline* PBR_LightingPipeline(PBR_LightingPass* lp);
 /* render.cpp:977-991 + 1119-1127: copies globals into the mapped buffer and records the pass; rows [row0,row1), row1 == 0 -> all */
 void PBR_RecordLightingPass(PBR_LightingPass* lp, GPU_Graph* graph, const PBR_Globals* globals, uint32_t row0, uint32_t row1);
 
+/* ---- voxel light grid + its sweep pass: render.cpp:678 (image), :816 (IMG0 binding), :151-187 (pipeline,
+ *      descriptor set), :1028 (clear), :1061-1072 (per-frame sweep) ---- */
+typedef struct PBR_Lightgrid PBR_Lightgrid;
+PBR_Lightgrid* PBR_MakeLightgrid(uint32_t size);                 /* reference: LIGHTGRID_SIZE 128 (render.cpp:7); size >= 128, multiple of 8 */
+void PBR_DestroyLightgrid(PBR_Lightgrid* lg);
+GPU_Texture* PBR_LightgridTexture(PBR_Lightgrid* lg);
+uint32_t PBR_LightgridSweepDirection(const PBR_Lightgrid* lg);   /* direction used by the last recorded sweep */
+void PBR_RecordLightgridClear(PBR_Lightgrid* lg, GPU_Graph* graph);
+/* advances the direction (1, 2, 0, 1, ... from a fresh grid, as render.cpp:1064-1065) and records the full dispatch */
+void PBR_RecordLightgridSweep(PBR_Lightgrid* lg, GPU_Graph* graph);
+/* sharded form: invocations (iy, iz) in [y0,y1) x [z0,z1) of an explicit direction; lines are independent */
+void PBR_RecordLightgridSweepLines(PBR_Lightgrid* lg, GPU_Graph* graph, uint32_t direction, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,13 @@ int pbrk_border_build(const void* pyramid, void* bordered, int W, int levels, vo
  * Z-up: u = atan2(y,x)/2pi + .5 (wraps), v = acos(z/|d|)/pi (clamps); bilinear; angles in fp64. */
 int pbrk_equirect_to_cube(const void* equirect_rgba32f, int w, int h, void* cube_level0, int size, void* stream);
 
+/* ---- K7: light-grid sweep, shaders/lightgrid_sweep.glsl:9-75 (dispatch render.cpp:1064-1072).
+ * image: RGBA16F [d][h][w], updated in place.  Invocations (iy, iz) in [y0,y1) x [z0,z1) each own one line of
+ * PBRK_SWEEP_LEN voxels: direction 0 -> (x, iy, iz), 1 -> (iz, x, iy), 2 -> (iy, iz, x).  The line axis must be at
+ * least PBRK_SWEEP_LEN long and the two ranges must lie inside the other two axes (checked; PBRK_E_ARG). */
+#define PBRK_SWEEP_LEN 128
+int pbrk_lightgrid_sweep(void* image_rgba16f, int w, int h, int d, int direction, int y0, int y1, int z0, int z1, void* stream);
+
 /* ---- K1: split-sum BRDF LUT (shaders/gen_brdf_integration_map.glsl:142-210).
  * angles4: device copy of pbrk_host_sample_angles(nsamples); view_cs: device float2[size] with
  * (cos, sin) of acos((x+.5)/size) computed on the host.  Rows [y0,y1) are written. */

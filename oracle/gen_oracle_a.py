@@ -71,7 +71,7 @@ def preprocess(text, lighting_variant=None):
 
     def binding(m):
         ind, name, typ, var = m.group(1), m.group(2), m.group(3), m.group(4)
-        if typ in ("imageCube", "image2D"):
+        if typ in ("imageCube", "image2D", "image3D"):
             return f"{ind}static {typ} {var};"
         return f"{ind}static {typ} {var} = {{{TEX_IDS.get(name, 0)}}};"
     t = re.sub(r"^(\s*)GPU_BINDING\((\w+)\)\s+(\w+)\s+(\w+);", binding, t, flags=re.M)
@@ -79,7 +79,9 @@ def preprocess(text, lighting_variant=None):
     t = re.sub(r"layout\(push_constant\)\s*uniform\s+\w+\s*\{", "static struct {", t)
     t = re.sub(r"layout\(location\s*=\s*\d+\)\s*(in|out)\s+", "static ", t)
     t = FLOAT_LIT.sub(r"\1f", t)
-    t = re.sub(r"\.(xyz|rgb|xy)\b", r".\1()", t)
+    # lightgrid_sweep.glsl assigns through a swizzle (`values[x].xyz += e;`): spell the write-back out
+    t = re.sub(r"(\w+\[[^\]]+\])\.xyz\s*([+-])=\s*([^;]+);", r"\1 = vec4(\1.xyz \2 (\3), \1.w);", t)
+    t = re.sub(r"\.(xyz|rgb|xy|yz|zxy|yzx)\b", r".\1()", t)
     t = t.replace("void main()", "void shader_main()")
     return t
 
@@ -208,7 +210,28 @@ int main(int argc, char** argv) {
 }
 """
 
-CXX = ["g++", "-std=c++17", "-O2", "-fno-fast-math", "-ffp-contract=off", "-w", f"-I{HERE}"]
+DRIVER_SWEEP = DRIVER_COMMON + r"""
+namespace S {
+#include "SHADER_INC"
+}
+// argv: w h d direction ny nz in_u16.bin out_u16.bin
+int main(int argc, char** argv) {
+    if (argc < 9) return 1;
+    int w = atoi(argv[1]), h = atoi(argv[2]), d = atoi(argv[3]), dir = atoi(argv[4]), ny = atoi(argv[5]), nz = atoi(argv[6]);
+    std::vector<uint16_t> img((size_t)w * h * d * 4);
+    FILE* f = fopen(argv[7], "rb"); if (!f || fread(img.data(), 2, img.size(), f) != img.size()) return 3; fclose(f);
+    S::LIGHTMAP_IMG.w = w; S::LIGHTMAP_IMG.h = h; S::LIGHTMAP_IMG.d = d; S::LIGHTMAP_IMG.data = img.data();
+    S::constants.X_direction = dir;
+    // invocations are independent (each touches only its own line), so the order does not matter
+    for (int iz = 0; iz < nz; iz++) for (int iy = 0; iy < ny; iy++) {
+        gl_GlobalInvocationID = uvec3{0u, (uint)iy, (uint)iz}; S::shader_main();
+    }
+    f = fopen(argv[8], "wb"); fwrite(img.data(), 2, img.size(), f); fclose(f);
+    return 0;
+}
+"""
+
+CXX = ["g++", "-std=c++17", "-mf16c", "-O2", "-fno-fast-math", "-ffp-contract=off", "-w", f"-I{HERE}"]
 
 
 def build(name, glsl, driver, defines=(), lighting_variant=None):
@@ -272,12 +295,64 @@ def run_lighting(exe, mode, W, H, globals_bytes, pixels, extra=()):
     return np.fromfile(op, dtype=np.float32).reshape(-1, 4)
 
 
+def sweep_inputs(seed, shape_dhw):
+    """Seeded light-grid contents: ~12 % occupied voxels (alpha 1, albedo-like colour), the rest carrying earlier light
+    (alpha 0), a few alpha == 0.5 voxels (neither branch of the shader's two alpha tests), one empty and one solid line."""
+    rng = np.random.default_rng(seed)
+    d, h, w = shape_dhw
+    g = np.zeros((d, h, w, 4), np.float16)
+    g[..., :3] = (rng.random((d, h, w, 3)) ** 2 * 4.0).astype(np.float16)
+    occ = rng.random((d, h, w)) < 0.12
+    g[occ, 3] = 1.0
+    g[occ, :3] = (rng.random((int(occ.sum()), 3)) * 3.0).astype(np.float16)
+    half = rng.random((d, h, w)) < 0.01
+    g[half, 3] = 0.5
+    dark = rng.random((d, h, w)) < 0.05
+    g[dark & ~occ, :3] = 0
+    return g
+
+
+def gen_sweep(meta):
+    import pbr_oracle as O
+    exe = build("sweep", "lightgrid_sweep.glsl", DRIVER_SWEEP)
+    entries = []
+    for direction, shape in ((0, (8, 8, 128)), (1, (8, 128, 8)), (2, (128, 8, 8))):
+        d, h, w = shape
+        g = sweep_inputs(0x5EED00B0 + direction, shape)
+        line_axis = {0: 2, 1: 1, 2: 0}[direction]
+        idx = [0, 0, 0]; idx[line_axis] = slice(None)
+        g[tuple(idx)] = 0                                   # an all-empty, all-dark line
+        idx = [1, 1, 1]; idx[line_axis] = slice(None)
+        g[tuple(idx) + (3,)] = 1.0                          # a fully occupied line
+        ny, nz = {0: (h, d), 1: (d, w), 2: (w, h)}[direction]
+        ip = os.path.join(SCRATCH, f"sweep_in_{direction}.bin")
+        op = os.path.join(SCRATCH, f"sweep_out_{direction}.bin")
+        g.view(np.uint16).tofile(ip)
+        subprocess.check_call([exe, str(w), str(h), str(d), str(direction), str(ny), str(nz), ip, op])
+        out = np.fromfile(op, dtype=np.uint16).reshape(d, h, w, 4)
+        np.savez_compressed(os.path.join(GOLDEN, f"oracle_a_sweep_dir{direction}.npz"), grid=g.view(np.uint16), swept=out)
+        mine = O.lightgrid_sweep(g.view(np.uint16), direction)
+        print("sweep dir", direction, "changed voxels", int((out != g.view(np.uint16)).any(axis=-1).sum()),
+              "oracle-B mismatches", int((mine != out).sum()))
+        entries.append({"file": f"oracle_a_sweep_dir{direction}.npz", "direction": direction, "shape_dhw": list(shape),
+                        "ny": ny, "nz": nz, "seed": 0x5EED00B0 + direction})
+    meta["lightgrid_sweep"] = {"shader": "lightgrid_sweep.glsl", "fixtures": entries,
+                               "note": "RGBA16F bit patterns; imageStore rounding = nearest-even (F16C), mix(x,y,a) = x*(1-a)+y*a"}
+
+
 def main():
     import pbr_oracle as O
     from pbrhip import synth
     import ctypes as C
 
     os.makedirs(GOLDEN, exist_ok=True)
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":       # regenerate one group, keep the rest of the metadata
+        with open(os.path.join(GOLDEN, "oracle_a_meta.json")) as f:
+            meta = json.load(f)
+        {"sweep": gen_sweep}[sys.argv[2]](meta)
+        with open(os.path.join(GOLDEN, "oracle_a_meta.json"), "w") as f:
+            json.dump(meta, f, indent=1)
+        return
     meta = {"generator": "oracle/gen_oracle_a.py", "reference": "uuwee/Vulkan-PBR-Renderer @ 2025-08-08",
             "note": "numbers produced by executing the reference GLSL text as C++ (glibc libm, fp32); "
                     "texture lookups are analytic or the oracle's sampler, as named per entry"}
@@ -384,6 +459,8 @@ def main():
         out = run_lighting(exes[variant], mode, 1920, 1080, gbytes, tile)
         np.save(os.path.join(GOLDEN, f"oracle_a_lighting_tile_{variant}.npy"), out)
     meta["lighting_tile"] = {"inputs": "oracle_a_lighting_tile_inputs.npy", "seed": 0x5EED00AC, "count": n}
+
+    gen_sweep(meta)
 
     with open(os.path.join(GOLDEN, "oracle_a_meta.json"), "w") as f:
         json.dump(meta, f, indent=1)

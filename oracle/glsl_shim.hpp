@@ -54,8 +54,18 @@ struct vec4 {
     vec3 rgb() const { return vec3(x, y, z); }
     vec2 xy() const { return vec2(x, y); }
 };
-struct uvec3 { uint x, y, z; uvec2 xy() const { return uvec2{x, y}; } };
-struct ivec3 { int x, y, z; ivec3() : x(0), y(0), z(0) {} ivec3(int a, int b, int c) : x(a), y(b), z(c) {} explicit ivec3(uvec3 u) : x(int(u.x)), y(int(u.y)), z(int(u.z)) {} };
+struct uvec3 { uint x, y, z; uvec2 xy() const { return uvec2{x, y}; } uvec2 yz() const { return uvec2{y, z}; } };
+struct ivec3 {
+    int x, y, z;
+    ivec3() : x(0), y(0), z(0) {}
+    ivec3(int a, int b, int c) : x(a), y(b), z(c) {}
+    ivec3(int a, uvec2 bc) : x(a), y(int(bc.x)), z(int(bc.y)) {}
+    explicit ivec3(uvec3 u) : x(int(u.x)), y(int(u.y)), z(int(u.z)) {}
+    ivec3 zxy() const { return ivec3(z, x, y); }
+    ivec3 yzx() const { return ivec3(y, z, x); }
+};
+inline ivec3 operator+(ivec3 a, ivec3 b) { return ivec3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline ivec3 operator*(int s, ivec3 a) { return ivec3(s * a.x, s * a.y, s * a.z); }
 
 // ---- operators --------------------------------------------------------------------------
 #define VOPS2(OP) \
@@ -165,6 +175,7 @@ struct texture2D { int id; };
 struct texture3D { int id; };
 struct imageCube { int size; float* data; };   // data: [6][size][size][4]
 struct image2D { int size; float* data; };     // data: [size][size][4]
+struct image3D { int w, h, d; uint16_t* data; };   // RGBA16F bit patterns, data: [d][h][w][4]
 struct H_cube { int id; };
 struct H_2d { int id; };
 struct H_3d { int id; };
@@ -193,6 +204,23 @@ inline void imageStore(image2D& im, ivec2 p, vec4 v) {
     float* o = im.data + (size_t(p.y) * im.size + p.x) * 4;
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
 }
+
+// RGBA16F storage image: loads widen, stores round to nearest-even (F16C hardware conversion, so this
+// is independent of the oracle's own fp16 code; the Vulkan driver's store rounding is not pinned by the reference)
+#if defined(__F16C__)
+typedef float shim_v4sf __attribute__((vector_size(16)));
+typedef short shim_v8hi __attribute__((vector_size(16)));
+inline float shim_h2f(uint16_t h) { shim_v8hi v = {short(h), 0, 0, 0, 0, 0, 0, 0}; return __builtin_ia32_vcvtph2ps(v)[0]; }
+inline uint16_t shim_f2h(float f) { shim_v4sf v = {f, 0, 0, 0}; return uint16_t(__builtin_ia32_vcvtps2ph(v, 0)[0]); }   // imm 0 = round to nearest even
+inline vec4 imageLoad(const image3D& im, ivec3 p) {
+    const uint16_t* v = im.data + ((size_t(p.z) * im.h + p.y) * im.w + p.x) * 4;
+    return vec4(shim_h2f(v[0]), shim_h2f(v[1]), shim_h2f(v[2]), shim_h2f(v[3]));
+}
+inline void imageStore(image3D& im, ivec3 p, vec4 v) {
+    uint16_t* o = im.data + ((size_t(p.z) * im.h + p.y) * im.w + p.x) * 4;
+    o[0] = shim_f2h(v.x); o[1] = shim_f2h(v.y); o[2] = shim_f2h(v.z); o[3] = shim_f2h(v.w);
+}
+#endif
 
 static uvec3 gl_GlobalInvocationID;
 static vec4 gl_FragCoord;

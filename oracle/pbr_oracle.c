@@ -826,3 +826,53 @@ void orc_shade(const OrcGlobals* g, const OrcShadeInputs* in, int flags,
             o[3] = 1.0f;
         }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * N2: light-grid sweep (lightgrid_sweep.glsl:9-75; dispatched by render.cpp:1064-1072 as (1,16,16)
+ * groups of 1x8x8 over a 128^3 RGBA16F image, X_direction cycling 0,1,2 per frame)
+ * ------------------------------------------------------------------------------------------ */
+void orc_lightgrid_sweep(uint16_t* img, int w, int h, int d, int direction, int ny, int nz) {
+    (void)d;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int iz = 0; iz < nz; ++iz)
+        for (int iy = 0; iy < ny; ++iy) {
+            /* :10-22 base coordinate and step */
+            int bx = 0, by = iy, bz = iz, sx = 1, sy = 0, sz = 0;
+            if (direction == 0) {}
+            else if (direction == 1) { int tx = bz, ty = bx, tz = by; bx = tx; by = ty; bz = tz; sx = 0; sy = 1; }
+            else { int tx = by, ty = bz, tz = bx; bx = tx; by = ty; bz = tz; sx = 0; sz = 1; }
+            const float SKY[3] = {1.0f, 1.2f, 2.0f};                                     /* :24 */
+            float old_v[ORC_SWEEP_LEN][4], val[ORC_SWEEP_LEN][4];
+            uint16_t* px[ORC_SWEEP_LEN];
+            for (int x = 0; x < ORC_SWEEP_LEN; ++x) {                                    /* :28-31 */
+                px[x] = img + (((size_t)(bz + x * sz) * h + (by + x * sy)) * w + (bx + x * sx)) * 4;
+                for (int c = 0; c < 4; ++c) old_v[x][c] = val[x][c] = orc_f16_to_f32(px[x][c]);
+            }
+            const float move_ratio = 0.5f;                                               /* :33 */
+            float m[3] = {SKY[0], SKY[1], SKY[2]};                                       /* :36 */
+            for (int x = 0; x < ORC_SWEEP_LEN; ++x) {                                    /* :37-48 */
+                if (old_v[x][3] > 0.5f) { m[0] = old_v[x][0]; m[1] = old_v[x][1]; m[2] = old_v[x][2]; }
+                else for (int c = 0; c < 3; ++c) {
+                    val[x][c] = val[x][c] + m[c];
+                    m[c] = move_ratio * val[x][c];
+                    val[x][c] = val[x][c] - m[c];
+                }
+            }
+            for (int c = 0; c < 3; ++c) val[ORC_SWEEP_LEN - 1][c] = val[ORC_SWEEP_LEN - 1][c] + m[c];   /* :49 */
+            m[0] = SKY[0]; m[1] = SKY[1]; m[2] = SKY[2];                                 /* :52 */
+            for (int x = ORC_SWEEP_LEN - 1; x >= 0; --x) {                               /* :53-66 */
+                if (old_v[x][3] > 0.5f) { m[0] = old_v[x][0]; m[1] = old_v[x][1]; m[2] = old_v[x][2]; }
+                else for (int c = 0; c < 3; ++c) {
+                    val[x][c] = val[x][c] + m[c];
+                    m[c] = move_ratio * val[x][c];
+                    val[x][c] = val[x][c] - m[c];
+                }
+            }
+            for (int c = 0; c < 3; ++c) val[0][c] = val[0][c] + m[c];                    /* :67 */
+            for (int x = 0; x < ORC_SWEEP_LEN; ++x) {                                    /* :70-75 */
+                if (old_v[x][3] < 0.5f)
+                    for (int c = 0; c < 4; ++c)
+                        px[x][c] = orc_f32_to_f16(old_v[x][c] * (1.0f - 0.35f) + val[x][c] * 0.35f);   /* mix(): x*(1-a)+y*a */
+            }
+        }
+}

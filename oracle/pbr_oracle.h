@@ -70,6 +70,14 @@ void   orc_env_analytic(const float dir[3], float out[4]);
 /* ---- extension (no reference counterpart): equirectangular RGBA32F [h][w][4] -> cube level 0 [6][size][size][4] ---- */
 void   orc_equirect_to_cube(const float* equirect, int w, int h, int size, float* out);
 
+/* ---- N2: voxel light-grid sweep, lightgrid_sweep.glsl:9-75 ----
+ * img: RGBA16F [d][h][w][4] (fp16 bit patterns), updated in place.  One invocation per (iy, iz) with
+ * iy < ny, iz < nz handles a 128-voxel line: direction 0 -> voxels (x, iy, iz); 1 -> (iz, x, iy)
+ * (base_coord.zxy, :15-18); 2 -> (iy, iz, x) (base_coord.yzx, :19-22).  imageLoad widens fp16 -> fp32,
+ * imageStore rounds to nearest-even (the reference leaves the rounding to the driver: unpinned). */
+#define ORC_SWEEP_LEN 128
+void   orc_lightgrid_sweep(uint16_t* img, int w, int h, int d, int direction, int ny, int nz);
+
 /* ---- A4/A5: per-sample tables (Fibonacci hemisphere; Beckmann weights) ---- */
 /* cs[i*4+0..3] = cos(pitch_i), sin(pitch_i), cos(yaw_i), sin(yaw_i)  (gen_prefiltered_env_map.glsl:125-128) */
 void   orc_sample_angles(int nsamples, float* cs);

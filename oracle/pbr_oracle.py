@@ -92,6 +92,8 @@ def lib():
     L.orc_f16_to_f32.argtypes = [C.c_uint16]
     L.orc_f16_to_f32.restype = C.c_float
     L.orc_equirect_to_cube.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p]
+    L.orc_lightgrid_sweep.argtypes = [np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS"), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_lightgrid_sweep.restype = None
     L.orc_shade.argtypes = [C.POINTER(OrcGlobals), C.POINTER(OrcShadeInputs), C.c_int,
                             C.c_int, C.c_int, C.c_int, C.c_int, f32p]
     _LIB = L
@@ -266,3 +268,15 @@ def shade(g, base, normal, orm, emissive, depth, flags=0, irradiance_cube=None, 
     x0, x1, y0, y1 = region if region is not None else (0, W, 0, H)
     lib().orc_shade(C.byref(g), C.byref(si), int(flags), x0, x1, y0, y1, out)
     return out
+
+
+def lightgrid_sweep(grid_half, direction, ny=None, nz=None):
+    """grid_half: uint16 [d][h][w][4] (RGBA16F bit patterns); returns the swept copy.  ny/nz default to the
+    full extent of the two non-line axes (direction 0: (h, d); 1: (d, w); 2: (w, h))."""
+    g = np.array(grid_half, dtype=np.uint16, order="C", copy=True)
+    d, h, w, _ = g.shape
+    full = {0: (h, d), 1: (d, w), 2: (w, h)}[int(direction)]
+    ny = full[0] if ny is None else ny
+    nz = full[1] if nz is None else nz
+    lib().orc_lightgrid_sweep(g.reshape(-1), w, h, d, int(direction), int(ny), int(nz))
+    return g

@@ -48,7 +48,7 @@ static void gpu_fail(const char* fmt, ...) {
 // object model
 // ------------------------------------------------------------------------------------------
 enum BindKind { Bind_Texture, Bind_Sampler, Bind_Buffer, Bind_StorageImage };
-enum KernelId { Kernel_None = 0, Kernel_BrdfLut, Kernel_Irradiance, Kernel_Prefilter, Kernel_Lighting };
+enum KernelId { Kernel_None = 0, Kernel_BrdfLut, Kernel_Irradiance, Kernel_Prefilter, Kernel_Lighting, Kernel_LightgridSweep };
 
 struct GPU_Sampler { GPU_SamplerDesc desc; bool shared; };
 
@@ -145,6 +145,7 @@ static const char kTokenLut[] = "HIPK1:gen_brdf_integration_map";
 static const char kTokenIrr[] = "HIPK3:gen_irradiance_map";
 static const char kTokenPre[] = "HIPK4:gen_prefiltered_env_map";
 static const char kTokenLit[] = "HIPK5:lighting_pass";
+static const char kTokenSweep[] = "HIPK7:lightgrid_sweep";
 
 // ------------------------------------------------------------------------------------------
 // formats  [gpu.h:99-144]
@@ -494,6 +495,7 @@ static KernelId identify_shader(const GPU_ShaderDesc* d) {
         if (t == kTokenIrr) return Kernel_Irradiance;
         if (t == kTokenPre) return Kernel_Prefilter;
         if (t == kTokenLit) return Kernel_Lighting;
+        if (t == kTokenSweep) return Kernel_LightgridSweep;
         return Kernel_None;
     }
     std::string b = basename_of(d->glsl_debug_filepath);
@@ -502,6 +504,7 @@ static KernelId identify_shader(const GPU_ShaderDesc* d) {
     if (b == "gen_irradiance_map.glsl" && glsl_contains(d->glsl, "CubemapSampleDirFromFaceUV") && glsl_contains(d->glsl, "TEX_ENV_CUBE")) return Kernel_Irradiance;
     if (b == "gen_prefiltered_env_map.glsl" && glsl_contains(d->glsl, "DistributionBeckmann") && glsl_contains(d->glsl, "mip_level")) return Kernel_Prefilter;
     if (b == "lighting_pass.glsl" && glsl_contains(d->glsl, "BRDF_INTEGRATION_MAP") && glsl_contains(d->glsl, "GBUFFER_DEPTH")) return Kernel_Lighting;
+    if (b == "lightgrid_sweep.glsl" && glsl_contains(d->glsl, "LIGHTMAP_IMG") && glsl_contains(d->glsl, "X_direction")) return Kernel_LightgridSweep;
     return Kernel_None;
 }
 static GPU_String token_for(KernelId k) {
@@ -510,6 +513,7 @@ static GPU_String token_for(KernelId k) {
     case Kernel_Irradiance: return GPU_String{kTokenIrr, sizeof kTokenIrr - 1};
     case Kernel_Prefilter: return GPU_String{kTokenPre, sizeof kTokenPre - 1};
     case Kernel_Lighting: return GPU_String{kTokenLit, sizeof kTokenLit - 1};
+    case Kernel_LightgridSweep: return GPU_String{kTokenSweep, sizeof kTokenSweep - 1};
     default: return GPU_String{nullptr, 0};
     }
 }
@@ -532,7 +536,7 @@ GPU_API GPU_String GPU_SPIRVFromGLSL(DS_Arena* arena, GPU_ShaderStage stage, GPU
     }
     snprintf(g_last_error_text, sizeof g_last_error_text,
              "the HIP backend has no built-in kernel for shader \"%s\" (stage %d); supported: gen_brdf_integration_map.glsl, "
-             "gen_irradiance_map.glsl, gen_prefiltered_env_map.glsl (compute), lighting_pass.glsl (full-screen)",
+             "gen_irradiance_map.glsl, gen_prefiltered_env_map.glsl, lightgrid_sweep.glsl (compute), lighting_pass.glsl (full-screen)",
              basename_of(desc->glsl_debug_filepath).c_str(), (int)stage);
     if (!out_errors) { gpu_fail("GPU_SPIRVFromGLSL: %s", g_last_error_text); return empty; }
     g_last_error.shader_stage = stage; g_last_error.line = 0;
@@ -558,8 +562,15 @@ GPU_API GPU_String GPU_JoinGLSLErrorString(DS_Arena* arena, GPU_GLSLErrorArray e
 GPU_API GPU_ComputePipeline* GPU_MakeComputePipeline(GPU_PipelineLayout* layout, const GPU_ShaderDesc* cs) {
     GPU_REQUIRE(layout && layout->finalized && cs, nullptr, "GPU_MakeComputePipeline: NULL / unfinalised argument");
     KernelId k = identify_shader(cs);
-    GPU_REQUIRE(k == Kernel_BrdfLut || k == Kernel_Irradiance || k == Kernel_Prefilter, nullptr,
+    GPU_REQUIRE(k == Kernel_BrdfLut || k == Kernel_Irradiance || k == Kernel_Prefilter || k == Kernel_LightgridSweep, nullptr,
                 "GPU_MakeComputePipeline: shader \"%s\" has no built-in HIP kernel", basename_of(cs->glsl_debug_filepath).c_str());
+    if (k == Kernel_LightgridSweep) {                                          // lightgrid_sweep.glsl:3 GPU_BINDING(IMG0) image3D
+        int b = find_binding(layout, "IMG0");
+        GPU_REQUIRE(b >= 0 && layout->bindings[b].kind == Bind_StorageImage, nullptr, "GPU_MakeComputePipeline: layout has no \"IMG0\" storage image");
+        GPU_ComputePipeline* p = new GPU_ComputePipeline();
+        p->layout = layout; p->kernel = k;
+        return p;
+    }
     GPU_REQUIRE(find_binding(layout, "OUTPUT") >= 0, nullptr, "GPU_MakeComputePipeline: layout has no \"OUTPUT\" storage image");
     if (k != Kernel_BrdfLut)
         GPU_REQUIRE(find_binding(layout, "TEX_ENV_CUBE") >= 0, nullptr, "GPU_MakeComputePipeline: layout has no \"TEX_ENV_CUBE\" texture");
@@ -697,6 +708,14 @@ static bool record_dispatch(GPU_Graph* g, Op& op, const char* fn) {
     op.kind = Op_Dispatch;
     op.cpipe = g->bound_cpipe; op.set = g->bound_cset;
     memcpy(op.push, g->push, g->push_size); op.push_size = g->push_size;
+    if (op.cpipe->kernel == Kernel_LightgridSweep) {
+        Slot* img = named_slot(op.set, "IMG0");
+        GPU_REQUIRE(img && img->tex, false, "%s: IMG0 is not bound", fn);
+        const GPU_Texture* t = &img->tex->base;
+        GPU_REQUIRE(t->format == GPU_Format_RGBA16F && t->layer_count == 1 && img->mip == 0, false, "%s: IMG0 must be mip 0 of an RGBA16F 3-D image", fn);
+        GPU_REQUIRE(op.push_size >= 4, false, "%s: the sweep needs its `int X_direction` push constant (lightgrid_sweep.glsl:5-7)", fn);
+        return true;
+    }
     Slot* out = named_slot(op.set, "OUTPUT");
     GPU_REQUIRE(out && out->tex, false, "%s: OUTPUT is not bound", fn);
     TextureImpl* ot = out->tex;
@@ -713,6 +732,36 @@ static bool record_dispatch(GPU_Graph* g, Op& op, const char* fn) {
     return true;
 }
 
+// Sweep invocations (iy, iz) in [y0,y1) x [z0,z1): checks that every voxel they touch lies inside the image
+// (direction 0 -> (x, iy, iz); 1 -> (iz, x, iy); 2 -> (iy, iz, x) with x < 128; lightgrid_sweep.glsl:10-22).
+// The op keeps the ranges in row0/row1 (iy) and face0/face1 (iz).
+static bool record_sweep_lines(GPU_Graph* g, Op& op, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1, const char* fn) {
+    (void)g;
+    const GPU_Texture* t = &named_slot(op.set, "IMG0")->tex->base;
+    int32_t dir; memcpy(&dir, op.push, 4);
+    if (dir < 0 || dir > 2) dir = 2;                                          // the shader's final `else` (:19)
+    uint32_t line_extent = dir == 0 ? t->width : (dir == 1 ? t->height : t->depth);
+    uint32_t y_extent = dir == 0 ? t->height : (dir == 1 ? t->depth : t->width);
+    uint32_t z_extent = dir == 0 ? t->depth : (dir == 1 ? t->width : t->height);
+    GPU_REQUIRE(y0 < y1 && z0 < z1, false, "%s: empty line range", fn);
+    GPU_REQUIRE(line_extent >= PBRK_SWEEP_LEN && y1 <= y_extent && z1 <= z_extent, false,
+                "%s: sweep direction %d over lines [%u,%u) x [%u,%u) leaves the %ux%ux%u image", fn, (int)dir, y0, y1, z0, z1, t->width, t->height, t->depth);
+    int32_t d32 = dir; memcpy(op.push, &d32, 4);
+    op.row0 = y0; op.row1 = y1; op.face0 = z0; op.face1 = z1;
+    return true;
+}
+
+GPU_API void GPUX_OpDispatchLines(GPU_Graph* g, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1) {
+    REC_GUARD(g);
+    GPU_REQUIRE_V(g->in_pass == nullptr, "GPUX_OpDispatchLines: inside a render pass");
+    Op op;
+    if (!record_dispatch(g, op, __func__)) return;
+    GPU_REQUIRE_V(op.cpipe->kernel == Kernel_LightgridSweep, "GPUX_OpDispatchLines: the bound pipeline is not the light-grid sweep");
+    if (!record_sweep_lines(g, op, y0, y1, z0, z1, __func__)) return;
+    op.rows_explicit = true;
+    g->ops.push_back(op);
+}
+
 GPU_API void GPU_OpDispatch(GPU_Graph* g, uint32_t gx, uint32_t gy, uint32_t gz) {
     REC_GUARD(g);
     GPU_REQUIRE_V(g->in_pass == nullptr, "GPU_OpDispatch: inside a render pass");
@@ -720,6 +769,13 @@ GPU_API void GPU_OpDispatch(GPU_Graph* g, uint32_t gx, uint32_t gy, uint32_t gz)
     Op op;
     if (!record_dispatch(g, op, __func__)) return;
     op.gx = gx; op.gy = gy; op.gz = gz;
+    if (op.cpipe->kernel == Kernel_LightgridSweep) {
+        // local size 1x8x8 (lightgrid_sweep.glsl:1); invocation x > 0 would redo line x = 0 (base_coord.x is the constant 0, :11)
+        GPU_REQUIRE_V(gx == 1, "GPU_OpDispatch: the sweep is dispatched as (1, gy, gz) (render.cpp:1072)");
+        if (!record_sweep_lines(g, op, 0, gy * 8, 0, gz * 8, __func__)) return;
+        g->ops.push_back(op);
+        return;
+    }
     Slot* out = named_slot(op.set, "OUTPUT");
     uint32_t size = mip_dim(out->tex->base.width, out->mip);
     // local size is 8x8x6 (shader line 1): the kernels work on whole rows, so the x extent must cover the image
@@ -734,6 +790,7 @@ GPU_API void GPUX_OpDispatchRows(GPU_Graph* g, uint32_t face0, uint32_t face1, u
     GPU_REQUIRE_V(g->in_pass == nullptr, "GPUX_OpDispatchRows: inside a render pass");
     Op op;
     if (!record_dispatch(g, op, __func__)) return;
+    GPU_REQUIRE_V(op.cpipe->kernel != Kernel_LightgridSweep, "GPUX_OpDispatchRows: use GPUX_OpDispatchLines for the light-grid sweep");
     Slot* out = named_slot(op.set, "OUTPUT");
     uint32_t size = mip_dim(out->tex->base.width, out->mip);
     GPU_REQUIRE_V(face0 < face1 && face1 <= out->tex->base.layer_count && row0 < row1 && row1 <= size,
@@ -992,6 +1049,16 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
     hipStream_t st = g->stream;
     switch (op.kind) {
     case Op_Dispatch: {
+        if (op.cpipe->kernel == Kernel_LightgridSweep) {
+            TextureImpl* it = named_slot(op.set, "IMG0")->tex;
+            int32_t dir; memcpy(&dir, op.push, 4);
+            timed(g, dir == 0 ? "K7.sweep_x" : (dir == 1 ? "K7.sweep_y" : "K7.sweep_z"), ev_used, [&] {
+                int rc = pbrk_lightgrid_sweep(it->dev, (int)it->base.width, (int)it->base.height, (int)it->base.depth, dir,
+                                              (int)op.row0, (int)op.row1, (int)op.face0, (int)op.face1, st);
+                if (rc != PBRK_OK) gpu_fail("K7 launch failed (%d)", rc);
+            });
+            return;
+        }
         Slot* out = named_slot(op.set, "OUTPUT");
         TextureImpl* ot = out->tex;
         uint32_t size = mip_dim(ot->base.width, out->mip);

@@ -134,6 +134,7 @@ PROTOTYPES = {
     "GPUX_GetFormatInfo": (None, None),
     "GPUX_SetDevice": (None, [C.c_int]), "GPUX_GetDevice": (C.c_int, []), "GPUX_SetErrorHandler": (None, [VP, VP]),
     "GPUX_BackendName": (C.c_char_p, []), "GPUX_OpDispatchRows": (None, [VP, U32, U32, U32, U32]),
+    "GPUX_OpDispatchLines": (None, [VP, U32, U32, U32, U32]),
     "GPUX_SetShadeFlags": (None, [VP, C.c_int]), "GPUX_OpDrawRows": (None, [VP, U32, U32]),
     "GPUX_OpCopyTextureMipToBuffer": (None, [VP, TexP, U32, BufP, U32]), "GPUX_OpCopyBufferToTextureMip": (None, [VP, BufP, U32, TexP, U32]),
     "GPUX_TextureMipBytes": (C.c_uint64, [TexP, U32]), "GPUX_TextureDevicePtr": (VP, [TexP, U32]), "GPUX_BufferDevicePtr": (VP, [BufP]),
@@ -160,6 +161,9 @@ PROTOTYPES = {
     "PBR_MakeLightingPass": (VP, [C.POINTER(PBR_GBuffer), C.POINTER(PBR_IBLMaps), U32, U32]), "PBR_DestroyLightingPass": (None, [VP]),
     "PBR_LightingGlobalsBuffer": (BufP, [VP]), "PBR_LightingPipeline": (VP, [VP]),
     "PBR_RecordLightingPass": (None, [VP, VP, C.POINTER(PBR_Globals), U32, U32]),
+    "PBR_MakeLightgrid": (VP, [U32]), "PBR_DestroyLightgrid": (None, [VP]), "PBR_LightgridTexture": (TexP, [VP]),
+    "PBR_LightgridSweepDirection": (U32, [VP]), "PBR_RecordLightgridClear": (None, [VP, VP]),
+    "PBR_RecordLightgridSweep": (None, [VP, VP]), "PBR_RecordLightgridSweepLines": (None, [VP, VP, U32, U32, U32, U32, U32]),
     # --- low-level kernel ABI (include/pbr_kernels.h) ---
     "pbrk_level_offset": (C.c_size_t, [C.c_int, C.c_int]), "pbrk_pyramid_texels": (C.c_size_t, [C.c_int, C.c_int]),
     "pbrk_bordered_level_offset": (C.c_size_t, [C.c_int, C.c_int]), "pbrk_bordered_pyramid_texels": (C.c_size_t, [C.c_int, C.c_int]),
@@ -168,6 +172,7 @@ PROTOTYPES = {
     "pbrk_host_irradiance_table": (C.c_int, [C.c_int, VP]),
     "pbrk_mip_chain": (C.c_int, [VP, C.c_int, C.c_int, VP]), "pbrk_box_downsample": (C.c_int, [VP, C.c_int, VP, C.c_int, VP]),
     "pbrk_border_build": (C.c_int, [VP, VP, C.c_int, C.c_int, VP]),
+    "pbrk_lightgrid_sweep": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "pbrk_brdf_lut": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, VP]),
     "pbrk_prefilter_copy": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "pbrk_mc_filter": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, C.c_float, C.c_float, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
@@ -241,7 +246,7 @@ def upload_mip(tex, mip, array):
 
 
 def read_mip(tex, mip=0):
-    """All layers of one mip -> numpy array [layers][h][w][c] (squeezed for single-layer textures)."""
+    """All layers of one mip -> numpy array [layers][h][w][c] (squeezed for single-layer textures; [d][h][w][c] for 3-D)."""
     L = lib()
     t = tex.contents
     nbytes = L.GPUX_TextureMipBytes(tex, mip)
@@ -253,10 +258,11 @@ def read_mip(tex, mip=0):
     dt, ch = _FMT_NP[t.format]
     w, h = max(1, t.width >> mip), max(1, t.height >> mip)
     raw = (C.c_char * nbytes).from_address(buf.contents.data)
-    arr = np.frombuffer(raw, dtype=dt).reshape(t.layer_count, h, w, ch).copy()
+    d = max(1, t.depth >> mip)
+    arr = np.frombuffer(raw, dtype=dt).reshape(t.layer_count * d, h, w, ch).copy()
     L.GPU_DestroyGraph(g)
     L.GPU_DestroyBuffer(buf)
-    return arr if t.layer_count > 1 else arr[0]
+    return arr if (t.layer_count > 1 or d > 1) else arr[0]
 
 
 def fill_globals(pos, ori=None, fov=75.0, aspect=16.0 / 9.0, near=0.02, far=1.0e4, sun_angle=(56.5, 97.0), frame_idx=0):

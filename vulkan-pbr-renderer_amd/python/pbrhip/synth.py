@@ -360,3 +360,36 @@ def synth_gbuffer_temple(width=7680, height=4320, seed=0x5EED0005, cam_pos=(0.0,
         emi[y0:y1, :, :3] = np.where(em[..., None], _encode_unorm8(np.stack([n2, 0.5 * n3, 0.2 * n1], axis=-1)), 0)
     return dict(base=base, normal=nrm, orm=orm, emissive=emi, depth=depth, camera=cam,
                 cam_pos=np.asarray(cam_pos, np.float64), ori_q=ori_q)
+
+
+def synth_lightgrid(size=128, seed=0x5EED00B7, lit=True):
+    """A voxelised-scene stand-in for the light grid (render.cpp:678, RGBA16F [z][y][x][4], returned as float16):
+    a ground slab, a few hollow boxes and pillars are occupied (alpha 1, rgb = the lit surface colour the
+    voxelize pass would write); empty voxels carry either nothing (lit=False: the frame-0 clear) or light from
+    earlier sweeps; a sprinkle of alpha == 0.5 voxels exercises the shader's two different alpha tests."""
+    rng = np.random.default_rng(seed)
+    n = size
+    g = np.zeros((n, n, n, 4), np.float16)
+    occ = np.zeros((n, n, n), bool)
+    occ[: max(2, n // 32)] = True                                     # ground slab (z is the first axis)
+    for _ in range(10):
+        lo = rng.integers(0, n - n // 4, 3)
+        ext = rng.integers(n // 16, n // 4, 3)
+        hi = np.minimum(lo + ext, n)
+        box = np.zeros_like(occ)
+        box[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = True
+        inner = np.zeros_like(occ)
+        inner[lo[0] + 1:hi[0] - 1, lo[1] + 1:hi[1] - 1, lo[2] + 1:hi[2] - 1] = True
+        occ |= box & ~inner                                           # shells, like rasterised surfaces
+    for _ in range(12):
+        y, x = rng.integers(0, n, 2)
+        occ[: rng.integers(n // 8, n // 2), y:y + 2, x:x + 2] = True   # pillars
+    colour = (rng.random((n, n, n, 3)) * np.array([2.5, 2.0, 1.5])).astype(np.float16)
+    g[..., :3] = np.where(occ[..., None], colour, 0)
+    g[..., 3] = occ
+    if lit:
+        glow = (rng.random((n, n, n, 3)) ** 3 * 3.0).astype(np.float16)
+        g[..., :3] = np.where(occ[..., None], g[..., :3], glow)
+    half = (rng.random((n, n, n)) < 0.002) & ~occ
+    g[half, 3] = 0.5
+    return g
