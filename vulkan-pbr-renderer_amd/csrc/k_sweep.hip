@@ -36,6 +36,15 @@ struct SweepGeom {
     int contiguous_lines;                // 1: xstride == 1 (sweep along x), 0: fstride == 1
 };
 
+#ifdef PBRK_SWEEP_PROFILE      // tools/ubench_sweep.hip only: per-block phase timestamps (wave 0) + placement
+__device__ unsigned long long* g_sweep_prof;
+#define SWEEP_STAMP(k) do { if (threadIdx.x == 0 && g_sweep_prof) { \
+    g_sweep_prof[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = wall_clock64(); \
+    g_sweep_prof[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + 8 + (k)] = clock64(); } } while (0)
+#else
+#define SWEEP_STAMP(k) do {} while (0)
+#endif
+
 __device__ __forceinline__ float half_bits_to_float(unsigned h) { return __half2float(__ushort_as_half((unsigned short)h)); }
 
 __global__ __launch_bounds__(256) void k_lightgrid_sweep(uint2* __restrict__ img, SweepGeom g) {
@@ -44,56 +53,109 @@ __global__ __launch_bounds__(256) void k_lightgrid_sweep(uint2* __restrict__ img
     const int f0 = blockIdx.x * kTile;
     const int nvalid = min(kTile, g.nf - f0);
     uint2* base = img + g.base + (long long)blockIdx.y * g.sstride + (long long)f0 * g.fstride;
+    SWEEP_STAMP(0);
 
     // ---- stage the tile: 32 x 8-B loads per thread, 512 B contiguous per wave-level load in every direction
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) {
-        int item = wave + 4 * i, l, x;
-        if (g.contiguous_lines) { l = item >> 1; x = lane + 64 * (item & 1); }
-        else { l = lane; x = item; }
-        if (l < nvalid) tile[x * kPitch + l] = base[(long long)l * g.fstride + (long long)x * g.xstride];
+    {
+        uint2 v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {                                        // all 32 loads in flight: one memory round trip
+            int item = wave + 4 * i, l, x;
+            if (g.contiguous_lines) { l = item >> 1; x = lane + 64 * (item & 1); }
+            else { l = lane; x = item; }
+            v[i] = make_uint2(0u, 0u);
+            if (l < nvalid) v[i] = base[(long long)l * g.fstride + (long long)x * g.xstride];
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            int item = wave + 4 * i, l, x;
+            if (g.contiguous_lines) { l = item >> 1; x = lane + 64 * (item & 1); }
+            else { l = lane; x = item; }
+            tile[x * kPitch + l] = v[i];
+        }
     }
+    SWEEP_STAMP(1);
     __syncthreads();
+    SWEEP_STAMP(2);
 
-    // ---- sweeps: wave c < 3 handles channel c of line `lane`
+    // ---- sweeps: wave c < 3 handles channel c of line `lane`.  LDS reads run one batch of kBatch steps ahead of the
+    //      dependent chain (the chain is the critical path: a wave alone on its SIMD cannot hide LDS latency otherwise).
     if (wave < 3 && lane < nvalid) {
-        const unsigned short* th = (const unsigned short*)tile;
-        unsigned short* tw = (unsigned short*)tile;
+        const unsigned short* th = (const unsigned short*)tile + lane * 4;
+        unsigned short* tw = (unsigned short*)tile + lane * 4;
         const int c = wave;
         const float sky = c == 0 ? 1.0f : (c == 1 ? 1.2f : 2.0f);            // :24 SKYLIGHT
         const float move_ratio = 0.5f;                                        // :33
-        float val[kLen];
+        constexpr int kBatch = 16, kBatches = kLen / kBatch;
+        // The shader's step for an empty voxel is  t = v + m;  m' = 0.5*t;  v' = t - m'.  Halving is exact in binary fp
+        // (no result here is near the fp32 subnormal range unless it is ~1e-30 below anything an fp16 store can see),
+        // so m' = fl(0.5*v + 0.5*m) = fmaf(0.5, m, 0.5*v) and v' = t - 0.5*t = m' bit for bit: the dependent chain is one
+        // FMA and one select per step, everything else is off the chain.  wv[x] holds 0.5 * (forward result of voxel x).
+        float wv[kLen];
+        unsigned cv[kBatch], ca[kBatch], nv[kBatch], na[kBatch];
         float m = sky;                                                        // :36
 #pragma unroll
-        for (int x = 0; x < kLen; ++x) {                                      // :37-48
-            int o = (x * kPitch + lane) * 4;
-            float ov = half_bits_to_float(th[o + c]), a = half_bits_to_float(th[o + 3]);
-            float tsum = ov + m;
-            float h = move_ratio * tsum;
-            float r = tsum - h;
-            bool occupied = a > 0.5f;
-            val[x] = occupied ? ov : r;
-            m = occupied ? ov : h;
+        for (int j = 0; j < kBatch; ++j) { cv[j] = th[j * kPitch * 4 + c]; ca[j] = th[j * kPitch * 4 + 3]; }
+#pragma unroll
+        for (int b = 0; b < kBatches; ++b) {                                  // :37-48
+            if (b + 1 < kBatches) {
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) {
+                    int x = (b + 1) * kBatch + j;
+                    nv[j] = th[x * kPitch * 4 + c]; na[j] = th[x * kPitch * 4 + 3];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                float ov = half_bits_to_float(cv[j]), a = half_bits_to_float(ca[j]);
+                float h = fmaf(move_ratio, m, move_ratio * ov);               // = 0.5 * (ov + m)
+                m = a > 0.5f ? ov : h;                                        // moving light, and the voxel's forward value
+                float w = move_ratio * m;
+                asm("" : "+v"(w));                                            // keep one value per step live, nothing else
+                wv[b * kBatch + j] = w;
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) { cv[j] = nv[j]; ca[j] = na[j]; }
         }
-        val[kLen - 1] = val[kLen - 1] + m;                                    // :49
+        wv[kLen - 1] = m;                                                     // :49 values[127] += moving_light: (m + m) * 0.5
+        SWEEP_STAMP(3);
         m = sky;                                                              // :52
         const float keep = 1.0f - 0.35f;                                      // mix(x, y, a) = x*(1-a) + y*a
 #pragma unroll
-        for (int x = kLen - 1; x >= 0; --x) {                                 // :53-66, fused with the store loop :70-75
-            int o = (x * kPitch + lane) * 4;
-            float ov = half_bits_to_float(th[o + c]), a = half_bits_to_float(th[o + 3]);
-            float tsum = val[x] + m;
-            float h = move_ratio * tsum;
-            float r = tsum - h;
-            bool occupied = a > 0.5f;
-            float v = occupied ? val[x] : r;
-            m = occupied ? ov : h;
-            if (x == 0) v = v + m;                                            // :67 (m is final here)
-            float mixed = ov * keep + v * 0.35f;
-            if (a < 0.5f) tw[o + c] = __half_as_ushort(__float2half_rn(mixed));
+        for (int j = 0; j < kBatch; ++j) {
+            int x = kLen - 1 - j;
+            cv[j] = th[x * kPitch * 4 + c]; ca[j] = th[x * kPitch * 4 + 3];
+        }
+#pragma unroll
+        for (int b = 0; b < kBatches; ++b) {                                  // :53-66, fused with the store loop :70-75
+            if (b + 1 < kBatches) {
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) {
+                    int x = kLen - 1 - ((b + 1) * kBatch + j);
+                    nv[j] = th[x * kPitch * 4 + c]; na[j] = th[x * kPitch * 4 + 3];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int x = kLen - 1 - (b * kBatch + j);
+                unsigned ab = ca[j];
+                asm("" : "+v"(ab));                                           // opaque: re-test alpha rather than carry 128 lane masks
+                float ov = half_bits_to_float(cv[j]), a = half_bits_to_float(ab);
+                float h = fmaf(move_ratio, m, wv[x]);                         // = 0.5 * (forward value + m) = the voxel's new value
+                m = a > 0.5f ? ov : h;
+                float v = h;
+                if (x == 0) v = v + m;                                        // :67 (m is final here)
+                float mixed = ov * keep + v * 0.35f;
+                unsigned short nb = __half_as_ushort(__float2half_rn(mixed));
+                tw[x * kPitch * 4 + c] = a < 0.5f ? nb : (unsigned short)cv[j];   // :72 (other voxels keep their bits)
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) { cv[j] = nv[j]; ca[j] = na[j]; }
         }
     }
+    SWEEP_STAMP(4);
     __syncthreads();
+    SWEEP_STAMP(5);
 
     // ---- write back the voxels the shader writes (:72 old alpha < 0.5; alpha itself is unchanged)
 #pragma unroll 8
@@ -106,6 +168,15 @@ __global__ __launch_bounds__(256) void k_lightgrid_sweep(uint2* __restrict__ img
             if (half_bits_to_float(v.y >> 16) < 0.5f) base[(long long)l * g.fstride + (long long)x * g.xstride] = v;
         }
     }
+    SWEEP_STAMP(6);
+#ifdef PBRK_SWEEP_PROFILE
+    if (threadIdx.x == 0 && g_sweep_prof) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_sweep_prof[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + 7] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 }
 }  // namespace
 
