@@ -329,6 +329,10 @@ def main():
         except Exception as e:      # the headline number must not depend on the extra
             extra["shade_error"] = repr(e)
         try:
+            extra["post_process"] = post_bench(L, pbrhip)
+        except Exception as e:
+            extra["post_process_error"] = repr(e)
+        try:
             extra["lightgrid_sweep"] = sweep_bench(L, pbrhip)
         except Exception as e:
             extra["lightgrid_sweep_error"] = repr(e)
@@ -416,6 +420,39 @@ def shade_bench(L, pbrhip, maps, world, frames=20):
            "roofline": {"kernel": "K5.shade", "bound": "hbm", "achieved": byt / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": byt / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}}
     L.GPU_DestroyGraph(g); L.PBR_DestroyLightingPass(lp); L.PBR_DestroyGBuffer(C.byref(gb))
+    return res
+
+
+def post_bench(L, pbrhip, frames=20):
+    """N3: 1920x1080 TAA resolve (K8) + tone-map pass (K9) of render.cpp:1131-1137, 1181-1187 on a synthetic HDR frame."""
+    from pbrhip import synth
+    W, H = 1920, 1080
+    lighting, depth, vel, vel_prev, history = synth.synth_post_inputs(0x5EED00D0, W, H)
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), W, H, pbrhip.Format_RGBA16F)
+    pp = L.PBR_MakePostProcess(C.byref(gb), W, H, pbrhip.Format_BGRA8UN)
+    pbrhip.upload_mip(gb.lighting_result, 0, lighting); pbrhip.upload_mip(gb.depth, 0, depth)
+    pbrhip.upload_mip(L.PBR_PostVelocity(pp, 0), 0, vel); pbrhip.upload_mip(L.PBR_PostVelocity(pp, 1), 0, vel_prev)
+    pbrhip.upload_mip(L.PBR_PostTaaOutput(pp, 1), 0, history)
+    g = L.GPU_MakeGraph()
+    L.PBR_RecordTaaResolve(pp, g, 0); L.PBR_RecordFinalPostProcess(pp, g, 0)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    for f in range(frames):
+        L.PBR_RecordTaaResolve(pp, g, f); L.PBR_RecordFinalPostProcess(pp, g, f)
+    t0 = time.perf_counter()
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    wall = time.perf_counter() - t0
+    ms = {}
+    for i in range(L.GPUX_GraphTimedOpCount(g)):
+        ms.setdefault(L.GPUX_GraphTimedOpName(g, i).decode(), []).append(L.GPUX_GraphTimedOpMs(g, i))
+    res = {"workload": "N3: 1920x1080 TAA resolve + tone map (RGBA16F in, BGRA8 out)", "frames": frames,
+           "mpixels_per_s_wall": W * H * frames / wall / 1e6, "kernels": []}
+    for name, byt in (("K8.taa_resolve", 36.0 * W * H), ("K9.final_post_process", 12.0 * W * H)):
+        k_ms = float(np.mean(ms[name]))
+        res["kernels"].append({"kernel": name, "avg_ms": k_ms, "bound": "hbm", "alg_bytes": byt,
+                               "achieved": byt / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": byt / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
+    L.GPU_DestroyGraph(g); L.PBR_DestroyPostProcess(pp); L.PBR_DestroyGBuffer(C.byref(gb))
     return res
 
 

@@ -122,6 +122,20 @@ void PBR_RecordLightgridSweep(PBR_Lightgrid* lg, GPU_Graph* graph);
 /* sharded form: invocations (iy, iz) in [y0,y1) x [z0,z1) of an explicit direction; lines are independent */
 void PBR_RecordLightgridSweepLines(PBR_Lightgrid* lg, GPU_Graph* graph, uint32_t direction, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1);
 
+/* ---- post-process tail: TAA resolve (render.cpp:281-337, 690-697, 732-739, 1131-1137) and the final
+ *      tone-map pass (render.cpp:456-501, 782-785, 1181-1187).  frame_idx selects the ping-pong half exactly as
+ *      frame_idx_mod2 does in the reference: frame i resolves into taa_output_rt[i%2] reading taa_output_rt[1-i%2]. ---- */
+typedef struct PBR_PostProcess PBR_PostProcess;
+/* gb supplies GBUFFER_DEPTH and LIGHTING_RESULT (RGBA16F); backbuffer_format stands in for the swapchain (RGBA8UN / BGRA8UN, or a float format) */
+PBR_PostProcess* PBR_MakePostProcess(const PBR_GBuffer* gb, uint32_t width, uint32_t height, GPU_Format backbuffer_format);
+void PBR_DestroyPostProcess(PBR_PostProcess* pp);
+GPU_Texture* PBR_PostVelocity(PBR_PostProcess* pp, uint32_t frame_idx_mod2);     /* gbuffer_velocity[i]: RG16F, uploaded by the caller */
+GPU_Texture* PBR_PostTaaOutput(PBR_PostProcess* pp, uint32_t frame_idx_mod2);    /* taa_output_rt[i] */
+GPU_Texture* PBR_PostBackbuffer(PBR_PostProcess* pp);
+void PBR_RecordTaaResolve(PBR_PostProcess* pp, GPU_Graph* graph, uint32_t frame_idx);
+void PBR_RecordTaaResolveRows(PBR_PostProcess* pp, GPU_Graph* graph, uint32_t frame_idx, uint32_t row0, uint32_t row1);   /* rows [row0,row1) only */
+void PBR_RecordFinalPostProcess(PBR_PostProcess* pp, GPU_Graph* graph, uint32_t frame_idx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,7 +35,10 @@ enum {                      /* output formats understood by the kernels */
     PBRK_FMT_RG16F = 1,
     PBRK_FMT_RG32F = 2,
     PBRK_FMT_RGBA16F = 3,
-    PBRK_FMT_RGBA32F = 4
+    PBRK_FMT_RGBA32F = 4,
+    PBRK_FMT_R32F = 5,      /* depth planes as sampled by the post-process passes */
+    PBRK_FMT_RGBA8UN = 6,
+    PBRK_FMT_BGRA8UN = 7
 };
 
 enum {                      /* shade flags (reference lighting_pass.glsl sub-blocks) */
@@ -137,6 +140,34 @@ typedef struct PbrkShadeArgs {
 int pbrk_shade(const PbrkShadeArgs* args, void* stream);
 /* LUT twin for K5: one 16-byte load per bilinear LUT fetch */
 int pbrk_lut_cells_build(const void* lut_half2, int size, void* cells_out, void* stream);
+
+/* ---- K8 / K9: post-process tail.  2-D sampler = linear clamp with coordinates snapped to 1/256
+ *      texel (Vulkan subTexelPrecisionBits = 8), exact fp32 lerps. ---- */
+typedef struct PbrkTex2D { const void* data; int format, width, height; } PbrkTex2D;     /* device pointer, PBRK_FMT_* */
+
+/* K8: shaders/taa_resolve.glsl:180-287 (3x3 Mitchell-Netravali resolve, variance clamp of the Catmull-Rom-filtered
+ * history, velocity / off-screen rejection).  All inputs and the target have the frame's size. */
+typedef struct PbrkTaaArgs {
+    PbrkTex2D lighting_result;          /* RGBA16F */
+    PbrkTex2D gbuffer_depth;            /* R32F */
+    PbrkTex2D gbuffer_velocity;         /* RG16F */
+    PbrkTex2D gbuffer_velocity_prev;    /* RG16F */
+    PbrkTex2D prev_frame_result;        /* RGBA16F */
+    void* out;                          /* half4 or float4 [height][width] */
+    int out_format;                     /* PBRK_FMT_RGBA16F / PBRK_FMT_RGBA32F */
+    int width, height, y0, y1;          /* rows [y0,y1) */
+} PbrkTaaArgs;
+int pbrk_taa_resolve(const PbrkTaaArgs* args, void* stream);
+
+/* K9: shaders/final_post_process.glsl:2-10,31-34: pow(aces_approx(2 * src), 1/2.2), alpha 1.  src may have another
+ * size than the target (bilinear); 8-bit targets round to nearest even. */
+typedef struct PbrkFinalArgs {
+    PbrkTex2D src;                      /* RGBA16F (bloom / TAA result) */
+    void* out;
+    int out_format;                     /* PBRK_FMT_RGBA8UN / BGRA8UN / RGBA16F / RGBA32F */
+    int width, height, y0, y1;
+} PbrkFinalArgs;
+int pbrk_final_post_process(const PbrkFinalArgs* args, void* stream);
 
 #ifdef __cplusplus
 }

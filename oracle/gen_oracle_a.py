@@ -36,6 +36,7 @@ TEX_IDS = {
     "TEX_ENV_CUBE": 1, "GBUFFER_BASE_COLOR": 10, "GBUFFER_NORMAL": 11, "GBUFFER_ORM": 12,
     "GBUFFER_EMISSIVE": 13, "GBUFFER_DEPTH": 14, "PREV_FRAME_RESULT": 15, "TEX_IRRADIANCE_MAP": 20,
     "PREFILTERED_ENV_MAP": 21, "BRDF_INTEGRATION_MAP": 22, "SUN_DEPTH_MAP": 23, "LIGHTGRID": 24,
+    "LIGHTING_RESULT": 30, "GBUFFER_VELOCITY": 31, "GBUFFER_VELOCITY_PREV": 32, "TEX0": 33,
 }
 
 FLOAT_LIT = re.compile(r"(?<![\w.])(\d+\.\d*(?:[eE][+-]?\d+)?|\.\d+(?:[eE][+-]?\d+)?|\d+[eE][+-]?\d+)(?![\w.])")
@@ -97,6 +98,7 @@ extern "C" {
 #include <vector>
 vec4 (*shim_cube_lookup)(int, vec3, float);
 vec4 (*shim_tex2d_lookup)(int, vec2, float);
+ivec2 (*shim_tex2d_size)(int);
 static std::vector<float> load_f32(const char* path) {
     FILE* f = fopen(path, "rb"); if (!f) { perror(path); exit(2); }
     fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
@@ -210,6 +212,42 @@ int main(int argc, char** argv) {
 }
 """
 
+DRIVER_POST = DRIVER_COMMON + r"""
+namespace S {
+#include "SHADER_INC"
+}
+// textures by binding id: 30 lighting (RGBA16F), 14 depth (R32F), 31/32 velocity (RG16F), 15 history (RGBA16F), 33 TEX0 (RGBA16F)
+static OrcTex2D g_tex[64];
+static std::vector<unsigned char> g_store[64];
+static vec4 tex2d_cb(int id, vec2 uv, float) { float o[4]; orc_tex2d_sample(&g_tex[id], uv.x, uv.y, o); return vec4(o[0], o[1], o[2], o[3]); }
+static ivec2 size_cb(int id) { return ivec2(g_tex[id].width, g_tex[id].height); }
+static void load_tex(int id, int fmt, int w, int h, const char* path) {
+    FILE* f = fopen(path, "rb"); if (!f) { perror(path); exit(2); }
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    g_store[id].resize(n); if (fread(g_store[id].data(), 1, n, f) != (size_t)n) exit(3); fclose(f);
+    g_tex[id].data = g_store[id].data(); g_tex[id].format = fmt; g_tex[id].width = w; g_tex[id].height = h;
+}
+// argv: kind(taa|final) W H out.bin  then per texture: id fmt w h path ...
+int main(int argc, char** argv) {
+    if (argc < 5) return 1;
+    int W = atoi(argv[2]), H = atoi(argv[3]);
+    for (int a = 5; a + 4 < argc + 0 + 1 && a + 4 <= argc - 0; a += 5) load_tex(atoi(argv[a]), atoi(argv[a + 1]), atoi(argv[a + 2]), atoi(argv[a + 3]), argv[a + 4]);
+    shim_tex2d_lookup = tex2d_cb; shim_tex2d_size = size_cb;
+    std::vector<float> out((size_t)W * H * 4);
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+        gl_FragCoord = vec4(x + 0.5f, y + 0.5f, 0.5f, 1.0f);
+#if defined(KIND_FINAL)
+        S::fs_uv = vec2((x + 0.5f) / (float)W, (y + 0.5f) / (float)H);
+#endif
+        S::shader_main();
+        float* o = &out[((size_t)y * W + x) * 4];
+        o[0] = S::out_color.x; o[1] = S::out_color.y; o[2] = S::out_color.z; o[3] = S::out_color.w;
+    }
+    save_f32(argv[4], out.data(), out.size());
+    return 0;
+}
+"""
+
 DRIVER_SWEEP = DRIVER_COMMON + r"""
 namespace S {
 #include "SHADER_INC"
@@ -246,7 +284,7 @@ def build(name, glsl, driver, defines=(), lighting_variant=None):
         f.write(driver.replace("SHADER_INC", inc))
     exe = os.path.join(SCRATCH, name)
     obj = os.path.join(SCRATCH, "pbr_oracle.o")
-    if not os.path.exists(obj):
+    if not os.path.exists(obj) or os.path.getmtime(obj) < os.path.getmtime(os.path.join(HERE, "pbr_oracle.c")):
         subprocess.check_call(["gcc", "-O2", "-fno-fast-math", "-ffp-contract=off", "-std=c11", "-c",
                                os.path.join(HERE, "pbr_oracle.c"), "-o", obj])
     subprocess.check_call(CXX + [f"-D{d}" for d in defines] + [src, obj, "-lm", "-o", exe])
@@ -340,6 +378,44 @@ def gen_sweep(meta):
                                "note": "RGBA16F bit patterns; imageStore rounding = nearest-even (F16C), mix(x,y,a) = x*(1-a)+y*a"}
 
 
+def gen_post(meta):
+    import pbr_oracle as O
+    W, H = 96, 54
+    from pbrhip import synth
+    lighting, depth, vel, vel_prev, history = synth.synth_post_inputs(0x5EED00C0, W, H)
+    files = {}
+    for name, arr in (("lighting", lighting), ("depth", depth), ("vel", vel), ("vel_prev", vel_prev), ("history", history)):
+        files[name] = os.path.join(SCRATCH, f"post_{name}.bin")
+        arr.tofile(files[name])
+    taa_exe = build("taa", "taa_resolve.glsl", DRIVER_POST, ["KIND_TAA"])
+    outp = os.path.join(SCRATCH, "taa_out.bin")
+    subprocess.check_call([taa_exe, "taa", str(W), str(H), outp,
+                           "30", "0", str(W), str(H), files["lighting"], "14", "2", str(W), str(H), files["depth"],
+                           "31", "1", str(W), str(H), files["vel"], "32", "1", str(W), str(H), files["vel_prev"],
+                           "15", "0", str(W), str(H), files["history"]])
+    taa = np.fromfile(outp, dtype=np.float32).reshape(H, W, 4)
+    mine = O.taa_resolve(lighting, depth, vel, vel_prev, history)
+    print("taa: oracle-B mismatching floats", int((mine.view(np.uint32) != taa.view(np.uint32)).sum()), "of", taa.size)
+    # tone map: input = the resolved frame stored as RGBA16F (what taa_output_rt holds), same size and half size
+    resolved = taa.astype(np.float16)
+    rp = os.path.join(SCRATCH, "post_resolved.bin")
+    resolved.tofile(rp)
+    fin_exe = build("final", "final_post_process.glsl", DRIVER_POST, ["KIND_FINAL"])
+    outs = {}
+    for tag, (ow, oh) in (("same", (W, H)), ("up", (W * 2, H * 2))):
+        subprocess.check_call([fin_exe, "final", str(ow), str(oh), outp, "33", "0", str(W), str(H), rp])
+        outs[tag] = np.fromfile(outp, dtype=np.float32).reshape(oh, ow, 4)
+        mine = O.final_post_process(resolved, ow, oh)
+        print("final", tag, "oracle-B mismatching floats", int((mine.view(np.uint32) != outs[tag].view(np.uint32)).sum()), "of", mine.size)
+    np.savez_compressed(os.path.join(GOLDEN, "oracle_a_post.npz"), lighting=lighting.view(np.uint16), depth=depth,
+                        velocity=vel.view(np.uint16), velocity_prev=vel_prev.view(np.uint16), history=history.view(np.uint16),
+                        taa=taa, final_same=outs["same"], final_up=outs["up"])
+    meta["post_process"] = {"file": "oracle_a_post.npz", "width": W, "height": H, "seed": 0x5EED00C0,
+                            "shaders": ["taa_resolve.glsl", "final_post_process.glsl"],
+                            "sampler": "oracle orc_tex2d_sample: linear clamp, coordinates snapped to 1/256 texel, exact fp32 lerps",
+                            "note": "final_* = tone map of the resolved frame stored as RGBA16F; final_up renders at 2x the source size"}
+
+
 def main():
     import pbr_oracle as O
     from pbrhip import synth
@@ -349,7 +425,7 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--only":       # regenerate one group, keep the rest of the metadata
         with open(os.path.join(GOLDEN, "oracle_a_meta.json")) as f:
             meta = json.load(f)
-        {"sweep": gen_sweep}[sys.argv[2]](meta)
+        {"sweep": gen_sweep, "post": gen_post}[sys.argv[2]](meta)
         with open(os.path.join(GOLDEN, "oracle_a_meta.json"), "w") as f:
             json.dump(meta, f, indent=1)
         return
@@ -461,6 +537,7 @@ def main():
     meta["lighting_tile"] = {"inputs": "oracle_a_lighting_tile_inputs.npy", "seed": 0x5EED00AC, "count": n}
 
     gen_sweep(meta)
+    gen_post(meta)
 
     with open(os.path.join(GOLDEN, "oracle_a_meta.json"), "w") as f:
         json.dump(meta, f, indent=1)

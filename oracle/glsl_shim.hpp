@@ -143,6 +143,13 @@ inline vec3 fract(vec3 a) { return vec3(fract(a.x), fract(a.y), fract(a.z)); }
 inline vec2 floor(vec2 a) { return vec2(floorf(a.x), floorf(a.y)); }
 inline vec3 floor(vec3 a) { return vec3(floorf(a.x), floorf(a.y), floorf(a.z)); }
 
+struct bvec2 { bool x, y; };
+inline bvec2 notEqual(vec2 a, vec2 b) { return bvec2{a.x != b.x, a.y != b.y}; }
+inline bool any(bvec2 b) { return b.x || b.y; }
+inline vec3 pow(vec3 a, vec3 b) { return vec3(powf(a.x, b.x), powf(a.y, b.y), powf(a.z, b.z)); }
+template <class B, ARITH(B)> inline vec3 max(vec3 a, B b) { return max(a, vec3(float(b))); }
+template <class B, class C, ARITH(B), ARITH(C)> inline vec2 clamp(vec2 v, B lo, C hi) { return clamp(v, vec2(float(lo)), vec2(float(hi))); }
+
 // ---- matrices (column-major, like GLSL) ---------------------------------------------------
 struct mat4 {
     float m[4][4]; // m[col][row]
@@ -191,6 +198,8 @@ extern vec4 (*shim_tex2d_lookup)(int id, vec2 uv, float lod);
 inline vec4 textureLod(H_cube h, vec3 d, float lod) { return shim_cube_lookup(h.id, d, lod); }
 inline vec4 textureLod(H_2d h, vec2 uv, float lod) { return shim_tex2d_lookup(h.id, uv, lod); }
 inline vec4 texture(H_2d h, vec2 uv) { return shim_tex2d_lookup(h.id, uv, 0.0f); }
+extern ivec2 (*shim_tex2d_size)(int id);
+inline ivec2 textureSize(H_2d h, int) { return shim_tex2d_size(h.id); }
 inline vec4 texture(H_3d, vec3) { return vec4(0.0f); }         // LIGHTGRID == 0 (out of scope)
 inline float texture(H_shadow, vec3) { return 1.0f; }          // shadow map == fully lit (out of scope)
 

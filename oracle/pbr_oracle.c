@@ -876,3 +876,142 @@ void orc_lightgrid_sweep(uint16_t* img, int w, int h, int d, int direction, int 
             }
         }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * N3: post-process tail
+ * ------------------------------------------------------------------------------------------ */
+static void tex2d_texel(const OrcTex2D* t, int i, int j, float o[4]) {
+    size_t idx = (size_t)j * t->width + i;
+    o[0] = o[1] = o[2] = 0.0f; o[3] = 1.0f;
+    switch (t->format) {
+    case ORC_TEX_RGBA16F: { const uint16_t* p = (const uint16_t*)t->data + idx * 4; for (int k = 0; k < 4; ++k) o[k] = orc_f16_to_f32(p[k]); break; }
+    case ORC_TEX_RG16F:   { const uint16_t* p = (const uint16_t*)t->data + idx * 2; o[0] = orc_f16_to_f32(p[0]); o[1] = orc_f16_to_f32(p[1]); break; }
+    case ORC_TEX_R32F:    { o[0] = ((const float*)t->data)[idx]; break; }
+    default:              { const float* p = (const float*)t->data + idx * 4; for (int k = 0; k < 4; ++k) o[k] = p[k]; break; }
+    }
+}
+
+void orc_tex2d_sample(const OrcTex2D* t, float u, float v, float out[4]) {
+    float fx = u * (float)t->width - 0.5f, fy = v * (float)t->height - 0.5f;
+    fx = floorf(fx * 256.0f + 0.5f) * (1.0f / 256.0f);           /* 8 sub-texel bits */
+    fy = floorf(fy * 256.0f + 0.5f) * (1.0f / 256.0f);
+    float flx = floorf(fx), fly = floorf(fy);
+    float a = fx - flx, b = fy - fly;
+    int i0 = (int)flx, j0 = (int)fly, i1 = i0 + 1, j1 = j0 + 1;
+    i0 = clampi(i0, 0, t->width - 1); i1 = clampi(i1, 0, t->width - 1);
+    j0 = clampi(j0, 0, t->height - 1); j1 = clampi(j1, 0, t->height - 1);
+    float t00[4], t10[4], t01[4], t11[4];
+    tex2d_texel(t, i0, j0, t00); tex2d_texel(t, i1, j0, t10); tex2d_texel(t, i0, j1, t01); tex2d_texel(t, i1, j1, t11);
+    for (int k = 0; k < 4; ++k) out[k] = lerpf(lerpf(t00[k], t10[k], a), lerpf(t01[k], t11[k], a), b);
+}
+
+static float mitchell_netravali(float x) {                        /* taa_resolve.glsl:13-26 */
+    float B = 1.0f / 3.0f, C = 1.0f / 3.0f;
+    float ax = fabsf(x);
+    if (ax < 1.0f)
+        return ((12.0f - 9.0f * B - 6.0f * C) * ax * ax * ax + (-18.0f + 12.0f * B + 6.0f * C) * ax * ax + (6.0f - 2.0f * B)) / 6.0f;
+    else if (ax >= 1.0f && ax < 2.0f)
+        return ((-B - 6.0f * C) * ax * ax * ax + (6.0f * B + 30.0f * C) * ax * ax + (-12.0f * B - 48.0f * C) * ax + (8.0f * B + 24.0f * C)) / 6.0f;
+    return 0.0f;
+}
+
+/* taa_resolve.glsl:133-178: Catmull-Rom history filter with 9 bilinear taps */
+static void history_catmull_rom(const OrcTex2D* hist, float uvx, float uvy, float tsx, float tsy, float out[4]) {
+    float sp[2] = {uvx * tsx, uvy * tsy}, ts[2] = {tsx, tsy};
+    float tp0[2], tp3[2], tp12[2], w0[2], w3[2], w12[2];
+    for (int k = 0; k < 2; ++k) {
+        float tp1 = floorf(sp[k] - 0.5f) + 0.5f;                                        /* :141 */
+        float f = sp[k] - tp1;                                                          /* :145 */
+        w0[k] = f * (-0.5f + f * (1.0f - 0.5f * f));                                    /* :150-153 */
+        float w1 = 1.0f + f * f * (-2.5f + 1.5f * f);
+        float w2 = f * (0.5f + f * (2.0f - 1.5f * f));
+        w3[k] = f * f * (-0.5f + 0.5f * f);
+        w12[k] = w1 + w2;                                                               /* :157-158 */
+        float offset12 = w2 / (w1 + w2);
+        tp0[k] = (tp1 - 1.0f) / ts[k];                                                  /* :161-167 */
+        tp3[k] = (tp1 + 2.0f) / ts[k];
+        tp12[k] = (tp1 + offset12) / ts[k];
+    }
+    const float* px[3] = {tp0, tp12, tp3}; const float* wx[3] = {w0, w12, w3};
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    for (int row = 0; row < 3; ++row)                                                   /* :170-180, row-major order */
+        for (int col = 0; col < 3; ++col) {
+            float s[4]; orc_tex2d_sample(hist, px[col][0], px[row][1], s);
+            for (int k = 0; k < 4; ++k) out[k] = out[k] + (s[k] * wx[col][0]) * wx[row][1];
+        }
+}
+
+void orc_taa_resolve(const OrcTaaInputs* in, int width, int height, int y0, int y1, float* out_rgba) {
+    (void)height;
+    #pragma omp parallel for schedule(static) num_threads(ORC_NT())
+    for (int py = y0; py < y1; ++py)
+        for (int px = 0; px < width; ++px) {
+            float tsx = (float)in->lighting_result.width, tsy = (float)in->lighting_result.height;   /* :189 */
+            float psx = 1.0f / tsx, psy = 1.0f / tsy;                                   /* :190 */
+            float uvx = ((float)px + 0.5f) * psx, uvy = ((float)py + 0.5f) * psy;       /* :192 */
+            float total[3] = {0, 0, 0}, wsum = 0.0f;
+            float nmin[3] = {10000, 10000, 10000}, nmax[3] = {-10000, -10000, -10000};
+            float m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
+            float closest_depth = 10000.0f, cdu = 0.0f, cdv = 0.0f;
+            for (int x = -1; x <= 1; ++x)                                               /* :205-227 */
+                for (int y = -1; y <= 1; ++y) {
+                    float su = uvx + (float)x * psx, sv = uvy + (float)y * psy;
+                    float nb[4]; orc_tex2d_sample(&in->lighting_result, su, sv, nb);
+                    float w = mitchell_netravali(sqrtf((float)x * (float)x + (float)y * (float)y));
+                    for (int k = 0; k < 3; ++k) {
+                        total[k] = total[k] + nb[k] * w;
+                        nmin[k] = fminf(nmin[k], nb[k]); nmax[k] = fmaxf(nmax[k], nb[k]);
+                        m1[k] = m1[k] + nb[k];
+                        m2[k] = m2[k] + nb[k] * nb[k];
+                    }
+                    wsum = wsum + w;
+                    float d[4]; orc_tex2d_sample(&in->gbuffer_depth, uvx, uvy, d);      /* :221 samples uv, not sample_uv */
+                    if (d[0] < closest_depth) { closest_depth = d[0]; cdu = su; cdv = sv; }
+                }
+            float src[3] = {total[0] / wsum, total[1] / wsum, total[2] / wsum};         /* :228 */
+            float vel[4]; orc_tex2d_sample(&in->gbuffer_velocity, cdu, cdv, vel);       /* :230 */
+            float ru = uvx - vel[0] * 0.5f, rv = uvy - vel[1] * 0.5f;                   /* :231 */
+            float pvel[4]; orc_tex2d_sample(&in->gbuffer_velocity_prev, ru, rv, pvel);  /* :232 */
+            float prev[4]; history_catmull_rom(&in->prev_frame_result, ru, rv, tsx, tsy, prev);   /* :234 */
+            const float inv9 = 1.0f / 9.0f, gamma = 1.0f;                               /* :237-238 */
+            for (int k = 0; k < 3; ++k) {                                               /* :239-244 */
+                float avg = m1[k] * inv9;
+                float sigma = sqrtf(fabsf(m2[k] * inv9 - avg * avg));
+                float minc = avg - gamma * sigma, maxc = avg + gamma * sigma;
+                prev[k] = fminf(fmaxf(prev[k], minc), maxc);
+            }
+            float wB = 0.05f, wA = 1.0f - wB;                                           /* :252-253 */
+            float dvx = pvel[0] - vel[0], dvy = pvel[1] - vel[1];
+            float velocity_diff = 1000.0f * sqrtf(dvx * dvx + dvy * dvy);               /* :269 */
+            wB = wB + velocity_diff;                                                    /* :270 */
+            float cu = fminf(fmaxf(ru, 0.0f), 1.0f), cv = fminf(fmaxf(rv, 0.0f), 1.0f);
+            if (ru != cu || rv != cv) { wA = 0.0f; wB = 1.0f; }                         /* :272-275 */
+            float* o = out_rgba + ((size_t)py * width + px) * 4;
+            float den = fmaxf(wB + wA, 0.00001f);
+            for (int k = 0; k < 3; ++k) o[k] = (src[k] * wB + prev[k] * wA) / den;      /* :277 */
+            o[3] = 1.0f;                                                                /* :290 */
+            (void)nmin; (void)nmax;
+        }
+}
+
+static float aces_approx(float v) {                                /* final_post_process.glsl:2-10 */
+    v = v * 0.6f;
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    return fminf(fmaxf((v * (a * v + b)) / (v * (c * v + d) + e), 0.0f), 1.0f);
+}
+
+void orc_final_post_process(const OrcTex2D* bloom_result, int width, int height, int y0, int y1, float* out_rgba) {
+    #pragma omp parallel for schedule(static) num_threads(ORC_NT())
+    for (int py = y0; py < y1; ++py)
+        for (int px = 0; px < width; ++px) {
+            float s[4]; orc_tex2d_sample(bloom_result, ((float)px + 0.5f) / (float)width, ((float)py + 0.5f) / (float)height, s);
+            float* o = out_rgba + ((size_t)py * width + px) * 4;
+            for (int k = 0; k < 3; ++k) o[k] = powf(aces_approx(2.0f * s[k]), 1.0f / 2.2f);   /* :32-33 */
+            o[3] = 1.0f;
+        }
+}
+
+uint8_t orc_unorm8(float v) {
+    v = fminf(fmaxf(v, 0.0f), 1.0f);
+    return (uint8_t)lrintf(v * 255.0f);                            /* round to nearest even (default rounding mode) */
+}

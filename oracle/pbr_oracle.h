@@ -78,6 +78,29 @@ void   orc_equirect_to_cube(const float* equirect, int w, int h, int size, float
 #define ORC_SWEEP_LEN 128
 void   orc_lightgrid_sweep(uint16_t* img, int w, int h, int d, int direction, int ny, int nz);
 
+/* ---- N3: post-process tail -- taa_resolve.glsl:180-287, final_post_process.glsl:2-10,31-34 ----
+ * 2-D sampler of these passes (SAMPLER_LINEAR_CLAMP; the reference leaves filtering to the driver: unpinned).  Defined
+ * here like the hardware the reference targets: texel coordinates are snapped to 1/256 texel (Vulkan
+ * subTexelPrecisionBits = 8) before the bilinear split, so a tap aimed at a texel centre returns that texel exactly;
+ * weights and lerps are then exact fp32 ( a + t*(b-a), x then y ), edges clamp. */
+enum { ORC_TEX_RGBA16F = 0, ORC_TEX_RG16F = 1, ORC_TEX_R32F = 2, ORC_TEX_RGBA32F = 3 };
+typedef struct OrcTex2D { const void* data; int format, width, height; } OrcTex2D;
+void   orc_tex2d_sample(const OrcTex2D* t, float u, float v, float out[4]);   /* missing channels: 0,0,0,1 */
+
+typedef struct OrcTaaInputs {
+    OrcTex2D lighting_result;      /* RGBA16F (render.cpp:693) */
+    OrcTex2D gbuffer_depth;        /* D32F as R32F (render.cpp:686-687) */
+    OrcTex2D gbuffer_velocity;     /* RG16F (render.cpp:690-691) */
+    OrcTex2D gbuffer_velocity_prev;
+    OrcTex2D prev_frame_result;    /* RGBA16F (render.cpp:696-697) */
+} OrcTaaInputs;
+/* out: float RGBA [y1-y0 rows are written in place][width][4] of a full-size array; gl_FragCoord = (x+.5, y+.5) */
+void   orc_taa_resolve(const OrcTaaInputs* in, int width, int height, int y0, int y1, float* out_rgba);
+/* fs_uv = ((x+.5)/width, (y+.5)/height) (full-screen triangle, final_post_process.glsl:16-19); out float RGBA */
+void   orc_final_post_process(const OrcTex2D* bloom_result, int width, int height, int y0, int y1, float* out_rgba);
+/* render-target conversion of a float colour to 8-bit unorm (round to nearest even of clamp(v,0,1)*255) */
+uint8_t orc_unorm8(float v);
+
 /* ---- A4/A5: per-sample tables (Fibonacci hemisphere; Beckmann weights) ---- */
 /* cs[i*4+0..3] = cos(pitch_i), sin(pitch_i), cos(yaw_i), sin(yaw_i)  (gen_prefiltered_env_map.glsl:125-128) */
 void   orc_sample_angles(int nsamples, float* cs);

@@ -37,6 +37,15 @@ class OrcGlobals(C.Structure):
 assert C.sizeof(OrcGlobals) == 552
 
 
+class OrcTex2D(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("format", C.c_int), ("width", C.c_int), ("height", C.c_int)]
+
+
+class OrcTaaInputs(C.Structure):
+    _fields_ = [("lighting_result", OrcTex2D), ("gbuffer_depth", OrcTex2D), ("gbuffer_velocity", OrcTex2D),
+                ("gbuffer_velocity_prev", OrcTex2D), ("prev_frame_result", OrcTex2D)]
+
+
 class OrcShadeInputs(C.Structure):
     _fields_ = [
         ("width", C.c_int), ("height", C.c_int),
@@ -94,6 +103,11 @@ def lib():
     L.orc_equirect_to_cube.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p]
     L.orc_lightgrid_sweep.argtypes = [np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS"), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.orc_lightgrid_sweep.restype = None
+    L.orc_tex2d_sample.argtypes = [C.POINTER(OrcTex2D), C.c_float, C.c_float, f32p]
+    L.orc_taa_resolve.argtypes = [C.POINTER(OrcTaaInputs), C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+    L.orc_final_post_process.argtypes = [C.POINTER(OrcTex2D), C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+    L.orc_unorm8.argtypes = [C.c_float]
+    L.orc_unorm8.restype = C.c_uint8
     L.orc_shade.argtypes = [C.POINTER(OrcGlobals), C.POINTER(OrcShadeInputs), C.c_int,
                             C.c_int, C.c_int, C.c_int, C.c_int, f32p]
     _LIB = L
@@ -280,3 +294,59 @@ def lightgrid_sweep(grid_half, direction, ny=None, nz=None):
     nz = full[1] if nz is None else nz
     lib().orc_lightgrid_sweep(g.reshape(-1), w, h, d, int(direction), int(ny), int(nz))
     return g
+
+
+TEX_RGBA16F, TEX_RG16F, TEX_R32F, TEX_RGBA32F = 0, 1, 2, 3
+
+
+def _tex2d(arr, fmt):
+    """arr: [h][w][c] (or [h][w]) numpy array already in the storage type of fmt; returns (OrcTex2D, keepalive)."""
+    want = {TEX_RGBA16F: (np.uint16, 4), TEX_RG16F: (np.uint16, 2), TEX_R32F: (np.float32, 1), TEX_RGBA32F: (np.float32, 4)}[fmt]
+    a = np.asarray(arr)
+    if a.dtype == np.float16:
+        a = a.view(np.uint16)
+    a = np.ascontiguousarray(a, dtype=want[0])
+    h, w = a.shape[:2]
+    assert a.size == h * w * want[1], (a.shape, fmt)
+    t = OrcTex2D()
+    t.data = a.ctypes.data_as(C.c_void_p)
+    t.format, t.width, t.height = fmt, w, h
+    return t, a
+
+
+def tex2d_sample(arr, fmt, u, v):
+    t, keep = _tex2d(arr, fmt)
+    out = np.zeros(4, np.float32)
+    lib().orc_tex2d_sample(C.byref(t), float(u), float(v), out)
+    return out
+
+
+def taa_resolve(lighting, depth, velocity, velocity_prev, history, rows=None):
+    """RGBA16F lighting/history, R32F depth, RG16F velocities (float16 or uint16 bit patterns) -> float32 [h][w][4]."""
+    ti = OrcTaaInputs()
+    keep = []
+    for name, arr, fmt in (("lighting_result", lighting, TEX_RGBA16F), ("gbuffer_depth", depth, TEX_R32F),
+                           ("gbuffer_velocity", velocity, TEX_RG16F), ("gbuffer_velocity_prev", velocity_prev, TEX_RG16F),
+                           ("prev_frame_result", history, TEX_RGBA16F)):
+        t, k = _tex2d(arr, fmt)
+        setattr(ti, name, t)
+        keep.append(k)
+    h, w = keep[0].shape[:2]
+    out = np.zeros((h, w, 4), np.float32)
+    y0, y1 = rows if rows is not None else (0, h)
+    lib().orc_taa_resolve(C.byref(ti), w, h, y0, y1, out.reshape(-1))
+    return out
+
+
+def final_post_process(src_rgba16f, width=None, height=None):
+    t, keep = _tex2d(src_rgba16f, TEX_RGBA16F)
+    h, w = keep.shape[:2]
+    width, height = width or w, height or h
+    out = np.zeros((height, width, 4), np.float32)
+    lib().orc_final_post_process(C.byref(t), width, height, 0, height, out.reshape(-1))
+    return out
+
+
+def unorm8(arr):
+    f = np.clip(np.asarray(arr, np.float32), 0.0, 1.0) * np.float32(255.0)
+    return np.rint(f).astype(np.uint8)                    # rint = round half to even, like lrintf

@@ -1,0 +1,199 @@
+"""Post-process tail: taa_resolve.glsl and final_post_process.glsl.  The oracle against the Oracle-A
+fixture (the shader text executed on the CPU, oracle/gen_oracle_a.py --only post) and the HIP kernels K8 / K9 against
+both, through the GPU_* boundary.  K8 is pure fp32 arithmetic in the shader's order: bit-exact.  K9 ends in pow():
+1e-5 relative on float targets, at most one code on 8-bit targets."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import pbr_oracle as O
+
+
+@pytest.fixture(scope="module")
+def post_fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, "oracle_a_post.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def test_oracle_matches_reference_shaders(post_fixture):
+    f = post_fixture
+    taa = O.taa_resolve(f["lighting"], f["depth"], f["velocity"], f["velocity_prev"], f["history"])
+    assert np.array_equal(taa.view(np.uint32), f["taa"].view(np.uint32))
+    resolved = f["taa"].astype(np.float16)
+    h, w = resolved.shape[:2]
+    assert np.array_equal(O.final_post_process(resolved).view(np.uint32), f["final_same"].view(np.uint32))
+    assert np.array_equal(O.final_post_process(resolved, 2 * w, 2 * h).view(np.uint32), f["final_up"].view(np.uint32))
+    # the fixture exercises both rejection paths and the negative Mitchell-Netravali lobes
+    lit = f["lighting"].view(np.float16).astype(np.float32)
+    assert (f["taa"][..., :3] < 0).any() and np.isfinite(f["taa"]).all()
+    assert np.abs(f["taa"][:, :4, :3] - lit[:, :4, :3]).max() < 400          # off-screen strip: result = source_sample only
+
+
+def test_post_sampler_definition():
+    rng = np.random.default_rng(5)
+    tex = rng.random((9, 13, 4)).astype(np.float16)
+    h, w = tex.shape[:2]
+    t32 = tex.astype(np.float32)
+    for (i, j) in [(0, 0), (12, 8), (5, 3), (7, 7)]:            # centre taps are exact texel fetches
+        got = O.tex2d_sample(tex, O.TEX_RGBA16F, (i + 0.5) / w, (j + 0.5) / h)
+        assert np.array_equal(got, t32[j, i])
+    # the same at a large extent, where fp32 coordinate error would otherwise bleed a neighbour in
+    big = np.zeros((2, 8192, 4), np.float16)
+    big[:, 8000] = [60000, 0, 0, 1]
+    got = O.tex2d_sample(big, O.TEX_RGBA16F, np.float32(7999.5) * np.float32(1.0 / 8192), 0.25)
+    assert got[0] == 0.0
+    assert np.array_equal(O.tex2d_sample(tex, O.TEX_RGBA16F, -3.0, 0.5 / h), t32[0, 0])       # clamp
+    assert np.array_equal(O.tex2d_sample(tex, O.TEX_RGBA16F, 7.0, 2.0), t32[h - 1, w - 1])
+    mid = O.tex2d_sample(tex, O.TEX_RGBA16F, 6.0 / w, 3.5 / h)                                # half way between texels 5 and 6
+    assert np.allclose(mid, t32[3, 5] + np.float32(0.5) * (t32[3, 6] - t32[3, 5]), rtol=0, atol=0)
+
+
+def test_taa_static_frame_is_a_fixed_point():
+    # constant colour, zero velocity, history == frame: every filter weight set sums to one -> output == input
+    h, w = 12, 20
+    frame = np.zeros((h, w, 4), np.float16); frame[..., :3] = [0.5, 1.25, 2.0]; frame[..., 3] = 1
+    vel = np.zeros((h, w, 2), np.float16)
+    depth = np.full((h, w), 0.999, np.float32)
+    out = O.taa_resolve(frame, depth, vel, vel, frame)
+    assert np.allclose(out[..., :3], [0.5, 1.25, 2.0], rtol=1e-6) and np.all(out[..., 3] == 1)
+    assert np.array_equal(O.unorm8(np.array([0.0, 0.5, 1.0, 2.0, -1.0, 0.5 / 255, 1.5 / 255])), [0, 128, 255, 255, 0, 0, 2])   # ties to even
+
+
+# ------------------------------------------------------------------------------------------- GPU
+
+def _upload(tex, arr):
+    import pbrhip
+    pbrhip.upload_mip(tex, 0, arr)
+
+
+def _tex2d(pbrhip, L, tex, fmt):
+    t = tex.contents
+    return pbrhip.PbrkTex2D(L.GPUX_TextureDevicePtr(tex, 0), fmt, t.width, t.height)
+
+
+@pytest.mark.gpu
+def test_gpu_taa_and_final_match_reference_shaders(gpu, post_fixture):
+    import pbrhip
+    L, f = gpu, post_fixture
+    h, w = f["depth"].shape
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), w, h, pbrhip.Format_RGBA16F)
+    pp = L.PBR_MakePostProcess(C.byref(gb), w, h, pbrhip.Format_RGBA8UN)
+    assert pp
+    _upload(gb.lighting_result, f["lighting"]); _upload(gb.depth, f["depth"])
+    frame_idx = 0
+    _upload(L.PBR_PostVelocity(pp, 0), f["velocity"]); _upload(L.PBR_PostVelocity(pp, 1), f["velocity_prev"])
+    _upload(L.PBR_PostTaaOutput(pp, 1), f["history"])
+    L.GPUX_EnableOpTiming(1)
+    g = L.GPU_MakeGraph()
+    L.PBR_RecordTaaResolve(pp, g, frame_idx)                                     # render.cpp:1131-1137
+    L.PBR_RecordFinalPostProcess(pp, g, frame_idx)                               # render.cpp:1181-1187
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    names = [L.GPUX_GraphTimedOpName(g, i).decode() for i in range(L.GPUX_GraphTimedOpCount(g))]
+    assert names == ["K8.taa_resolve", "K9.final_post_process"]
+    L.GPU_DestroyGraph(g)
+    taa = pbrhip.read_mip(L.PBR_PostTaaOutput(pp, 0), 0)
+    want = f["taa"].astype(np.float16)
+    assert np.array_equal(taa.view(np.uint16), want.view(np.uint16)), "TAA RGBA16F bits"
+    bb = pbrhip.read_mip(L.PBR_PostBackbuffer(pp), 0)
+    want8 = O.unorm8(f["final_same"])
+    diff = np.abs(bb.astype(np.int32) - want8.astype(np.int32))
+    assert diff.max() <= 1 and (diff == 0).mean() > 0.995, (diff.max(), (diff == 0).mean())
+    assert np.all(bb[..., 3] == 255)
+
+    # raw kernels on float targets: K8 bit-exact in fp32, K9 within pow() accuracy; also a 2x upscaling final pass
+    out32 = pbrhip.make_texture(pbrhip.Format_RGBA32F, w, h, pbrhip.TextureFlag_RenderTarget)
+    a = pbrhip.PbrkTaaArgs(_tex2d(pbrhip, L, gb.lighting_result, pbrhip.PBRK_FMT_RGBA16F), _tex2d(pbrhip, L, gb.depth, pbrhip.PBRK_FMT_R32F),
+                           _tex2d(pbrhip, L, L.PBR_PostVelocity(pp, 0), pbrhip.PBRK_FMT_RG16F), _tex2d(pbrhip, L, L.PBR_PostVelocity(pp, 1), pbrhip.PBRK_FMT_RG16F),
+                           _tex2d(pbrhip, L, L.PBR_PostTaaOutput(pp, 1), pbrhip.PBRK_FMT_RGBA16F), L.GPUX_TextureDevicePtr(out32, 0),
+                           pbrhip.PBRK_FMT_RGBA32F, w, h, 0, h)
+    assert L.pbrk_taa_resolve(C.byref(a), None) == 0
+    L.GPU_WaitUntilIdle()
+    got = pbrhip.read_mip(out32, 0)
+    assert np.array_equal(got.view(np.uint32), f["taa"].view(np.uint32)), "TAA fp32 bits"
+    up = pbrhip.make_texture(pbrhip.Format_RGBA32F, 2 * w, 2 * h, pbrhip.TextureFlag_RenderTarget)
+    for target, key, (ow, oh) in ((out32, "final_same", (w, h)), (up, "final_up", (2 * w, 2 * h))):
+        fa = pbrhip.PbrkFinalArgs(_tex2d(pbrhip, L, L.PBR_PostTaaOutput(pp, 0), pbrhip.PBRK_FMT_RGBA16F), L.GPUX_TextureDevicePtr(target, 0),
+                                  pbrhip.PBRK_FMT_RGBA32F, ow, oh, 0, oh)
+        assert L.pbrk_final_post_process(C.byref(fa), None) == 0
+        L.GPU_WaitUntilIdle()
+        got = pbrhip.read_mip(target, 0)
+        rel = np.abs(got - f[key]) / np.maximum(f[key], 1e-3)
+        assert rel.max() < 1e-5, (key, rel.max())
+    # argument checks of the raw entry points (no launch on bad shapes)
+    a.y1 = h + 1; assert L.pbrk_taa_resolve(C.byref(a), None) == -1
+    a.y1 = h; a.out_format = pbrhip.PBRK_FMT_RGBA8UN; assert L.pbrk_taa_resolve(C.byref(a), None) == -2
+    a.out_format = pbrhip.PBRK_FMT_RGBA32F; a.gbuffer_depth.width = w - 1; assert L.pbrk_taa_resolve(C.byref(a), None) == -1
+    L.GPU_DestroyTexture(out32); L.GPU_DestroyTexture(up)
+    L.PBR_DestroyPostProcess(pp); L.PBR_DestroyGBuffer(C.byref(gb))
+
+
+@pytest.mark.gpu
+def test_gpu_post_full_frame_sequence(gpu):
+    """1920x1080: three frames of lighting -> TAA (ping-pong history) -> tone map, checked against the oracle on bands of rows
+    each frame (bit-exact RGBA16F), plus row-sharded draws == full draws."""
+    import pbrhip
+    from pbrhip.synth import synth_post_inputs as post_inputs
+    L = gpu
+    W, H = 1920, 1080
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), W, H, pbrhip.Format_RGBA16F)
+    pp = L.PBR_MakePostProcess(C.byref(gb), W, H, pbrhip.Format_BGRA8UN)
+    history = np.zeros((H, W, 4), np.float16)                                    # frame 0 reads the zero-initialised taa_output_rt[1]
+    vel_prev = np.zeros((H, W, 2), np.float16)
+    bands = [(0, 6), (537, 543), (1074, 1080)]
+    for frame in range(3):
+        lighting, depth, vel, _, _ = post_inputs(0x5EED00D0 + frame, W, H)
+        _upload(gb.lighting_result, lighting); _upload(gb.depth, depth)
+        _upload(L.PBR_PostVelocity(pp, frame % 2), vel)
+        g = L.GPU_MakeGraph()
+        L.PBR_RecordTaaResolve(pp, g, frame)
+        L.PBR_RecordFinalPostProcess(pp, g, frame)
+        L.GPU_GraphSubmit(g); L.GPU_GraphWait(g); L.GPU_DestroyGraph(g)
+        got = pbrhip.read_mip(L.PBR_PostTaaOutput(pp, frame % 2), 0)
+        assert np.isfinite(got.astype(np.float32)).all()
+        for (y0, y1) in bands:
+            want = O.taa_resolve(lighting, depth, vel, vel_prev, history, rows=(y0, y1))[y0:y1].astype(np.float16)
+            assert np.array_equal(got[y0:y1].view(np.uint16), want.view(np.uint16)), f"frame {frame} rows {y0}:{y1}"
+        bb = pbrhip.read_mip(L.PBR_PostBackbuffer(pp), 0)
+        y0, y1 = bands[1]
+        want8 = O.unorm8(O.final_post_process(got)[y0:y1])[..., [2, 1, 0, 3]]    # BGRA byte order
+        assert np.abs(bb[y0:y1].astype(np.int32) - want8.astype(np.int32)).max() <= 1
+        history, vel_prev = got, vel
+    # row-sharded resolve (screen bands) == the full draw of the last frame
+    frame = 2
+    full = got
+    scratch = np.zeros_like(full)
+    _upload(L.PBR_PostTaaOutput(pp, frame % 2), scratch)
+    g = L.GPU_MakeGraph()
+    for (r0, r1) in ((0, 400), (400, 401), (401, H)):
+        # the reference's own call sequence with the draw replaced by its row-restricted form
+        L.PBR_RecordTaaResolveRows(pp, g, frame, r0, r1)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g); L.GPU_DestroyGraph(g)
+    assert np.array_equal(pbrhip.read_mip(L.PBR_PostTaaOutput(pp, frame % 2), 0).view(np.uint16), full.view(np.uint16))
+    L.PBR_DestroyPostProcess(pp); L.PBR_DestroyGBuffer(C.byref(gb))
+
+
+@pytest.mark.gpu
+def test_gpu_post_boundary_errors(gpu):
+    import pbrhip
+    L = gpu
+    msgs = []
+    CB = C.CFUNCTYPE(None, C.c_char_p, C.c_void_p)
+    cb = CB(lambda m, u: msgs.append(m.decode()))
+    L.GPUX_SetErrorHandler(C.cast(cb, C.c_void_p), None)
+    try:
+        W, H = 64, 32
+        gb = pbrhip.PBR_GBuffer()
+        L.PBR_MakeGBuffer(C.byref(gb), W, H, pbrhip.Format_RGBA32F)              # lighting result in the wrong format for the TAA pass
+        pp = L.PBR_MakePostProcess(C.byref(gb), W, H, pbrhip.Format_RGBA8UN)
+        assert pp and not msgs
+        g = L.GPU_MakeGraph()
+        n = len(msgs); L.PBR_RecordTaaResolve(pp, g, 0); assert len(msgs) == n + 1 and "LIGHTING_RESULT" in msgs[-1]
+        n = len(msgs); L.PBR_RecordFinalPostProcess(pp, g, 0); assert len(msgs) == n        # the final pass does not read it
+        L.GPU_GraphSubmit(g); L.GPU_GraphWait(g); L.GPU_DestroyGraph(g)
+        L.PBR_DestroyPostProcess(pp); L.PBR_DestroyGBuffer(C.byref(gb))
+    finally:
+        L.GPUX_SetErrorHandler(None, None)

@@ -48,7 +48,7 @@ static void gpu_fail(const char* fmt, ...) {
 // object model
 // ------------------------------------------------------------------------------------------
 enum BindKind { Bind_Texture, Bind_Sampler, Bind_Buffer, Bind_StorageImage };
-enum KernelId { Kernel_None = 0, Kernel_BrdfLut, Kernel_Irradiance, Kernel_Prefilter, Kernel_Lighting, Kernel_LightgridSweep };
+enum KernelId { Kernel_None = 0, Kernel_BrdfLut, Kernel_Irradiance, Kernel_Prefilter, Kernel_Lighting, Kernel_LightgridSweep, Kernel_TaaResolve, Kernel_FinalPost };
 
 struct GPU_Sampler { GPU_SamplerDesc desc; bool shared; };
 
@@ -146,6 +146,8 @@ static const char kTokenIrr[] = "HIPK3:gen_irradiance_map";
 static const char kTokenPre[] = "HIPK4:gen_prefiltered_env_map";
 static const char kTokenLit[] = "HIPK5:lighting_pass";
 static const char kTokenSweep[] = "HIPK7:lightgrid_sweep";
+static const char kTokenTaa[] = "HIPK8:taa_resolve";
+static const char kTokenFinal[] = "HIPK9:final_post_process";
 
 // ------------------------------------------------------------------------------------------
 // formats  [gpu.h:99-144]
@@ -496,6 +498,8 @@ static KernelId identify_shader(const GPU_ShaderDesc* d) {
         if (t == kTokenPre) return Kernel_Prefilter;
         if (t == kTokenLit) return Kernel_Lighting;
         if (t == kTokenSweep) return Kernel_LightgridSweep;
+        if (t == kTokenTaa) return Kernel_TaaResolve;
+        if (t == kTokenFinal) return Kernel_FinalPost;
         return Kernel_None;
     }
     std::string b = basename_of(d->glsl_debug_filepath);
@@ -504,6 +508,8 @@ static KernelId identify_shader(const GPU_ShaderDesc* d) {
     if (b == "gen_irradiance_map.glsl" && glsl_contains(d->glsl, "CubemapSampleDirFromFaceUV") && glsl_contains(d->glsl, "TEX_ENV_CUBE")) return Kernel_Irradiance;
     if (b == "gen_prefiltered_env_map.glsl" && glsl_contains(d->glsl, "DistributionBeckmann") && glsl_contains(d->glsl, "mip_level")) return Kernel_Prefilter;
     if (b == "lighting_pass.glsl" && glsl_contains(d->glsl, "BRDF_INTEGRATION_MAP") && glsl_contains(d->glsl, "GBUFFER_DEPTH")) return Kernel_Lighting;
+    if (b == "taa_resolve.glsl" && glsl_contains(d->glsl, "SampleHistoryTextureCatmullRom") && glsl_contains(d->glsl, "GBUFFER_VELOCITY_PREV")) return Kernel_TaaResolve;
+    if (b == "final_post_process.glsl" && glsl_contains(d->glsl, "aces_approx") && glsl_contains(d->glsl, "BLOOM_RESULT")) return Kernel_FinalPost;
     if (b == "lightgrid_sweep.glsl" && glsl_contains(d->glsl, "LIGHTMAP_IMG") && glsl_contains(d->glsl, "X_direction")) return Kernel_LightgridSweep;
     return Kernel_None;
 }
@@ -514,6 +520,8 @@ static GPU_String token_for(KernelId k) {
     case Kernel_Prefilter: return GPU_String{kTokenPre, sizeof kTokenPre - 1};
     case Kernel_Lighting: return GPU_String{kTokenLit, sizeof kTokenLit - 1};
     case Kernel_LightgridSweep: return GPU_String{kTokenSweep, sizeof kTokenSweep - 1};
+    case Kernel_TaaResolve: return GPU_String{kTokenTaa, sizeof kTokenTaa - 1};
+    case Kernel_FinalPost: return GPU_String{kTokenFinal, sizeof kTokenFinal - 1};
     default: return GPU_String{nullptr, 0};
     }
 }
@@ -528,7 +536,7 @@ GPU_API GPU_String GPU_SPIRVFromGLSL(DS_Arena* arena, GPU_ShaderStage stage, GPU
     GPU_ShaderDesc probe = *desc;
     probe.spirv = empty;
     KernelId k = identify_shader(&probe);
-    bool stage_ok = (k == Kernel_Lighting) ? (stage == GPU_ShaderStage_Vertex || stage == GPU_ShaderStage_Fragment)
+    bool stage_ok = (k == Kernel_Lighting || k == Kernel_TaaResolve || k == Kernel_FinalPost) ? (stage == GPU_ShaderStage_Vertex || stage == GPU_ShaderStage_Fragment)
                                            : (stage == GPU_ShaderStage_Compute);
     if (k != Kernel_None && stage_ok) {
         if (out_errors) { out_errors->data = nullptr; out_errors->length = 0; }
@@ -536,7 +544,7 @@ GPU_API GPU_String GPU_SPIRVFromGLSL(DS_Arena* arena, GPU_ShaderStage stage, GPU
     }
     snprintf(g_last_error_text, sizeof g_last_error_text,
              "the HIP backend has no built-in kernel for shader \"%s\" (stage %d); supported: gen_brdf_integration_map.glsl, "
-             "gen_irradiance_map.glsl, gen_prefiltered_env_map.glsl, lightgrid_sweep.glsl (compute), lighting_pass.glsl (full-screen)",
+             "gen_irradiance_map.glsl, gen_prefiltered_env_map.glsl, lightgrid_sweep.glsl (compute), lighting_pass.glsl, taa_resolve.glsl, final_post_process.glsl (full-screen)",
              basename_of(desc->glsl_debug_filepath).c_str(), (int)stage);
     if (!out_errors) { gpu_fail("GPU_SPIRVFromGLSL: %s", g_last_error_text); return empty; }
     g_last_error.shader_stage = stage; g_last_error.line = 0;
@@ -588,6 +596,10 @@ GPU_API GPU_RenderPass* GPU_MakeRenderPass(const GPU_RenderPassDesc* desc) {
     rp->desc = *desc;
     for (uint32_t i = 0; i < desc->color_targets_count; ++i) rp->targets.push_back(desc->color_targets[i]);
     rp->desc.color_targets = rp->targets.data();
+    if ((rp->desc.width == 0 || rp->desc.height == 0) && !rp->targets.empty() && rp->targets[0].texture) {   // size left to the target (the swapchain pass, render.cpp:782-785)
+        rp->desc.width = mip_dim(rp->targets[0].texture->width, rp->targets[0].mip_level);
+        rp->desc.height = mip_dim(rp->targets[0].texture->height, rp->targets[0].mip_level);
+    }
     return rp;
 }
 GPU_API void GPU_DestroyRenderPass(GPU_RenderPass* rp) { delete rp; }
@@ -595,11 +607,11 @@ GPU_API void GPU_DestroyRenderPass(GPU_RenderPass* rp) { delete rp; }
 GPU_API GPU_GraphicsPipeline* GPU_MakeGraphicsPipeline(const GPU_GraphicsPipelineDesc* desc) {
     GPU_REQUIRE(desc && desc->layout && desc->render_pass, nullptr, "GPU_MakeGraphicsPipeline: NULL argument");
     KernelId k = identify_shader(&desc->fs);
-    GPU_REQUIRE(k == Kernel_Lighting, nullptr,
-                "GPU_MakeGraphicsPipeline: unsupported (raster): only the full-screen lighting_pass.glsl pipeline has a HIP kernel (got \"%s\")",
+    GPU_REQUIRE(k == Kernel_Lighting || k == Kernel_TaaResolve || k == Kernel_FinalPost, nullptr,
+                "GPU_MakeGraphicsPipeline: unsupported (raster): only the full-screen lighting_pass / taa_resolve / final_post_process pipelines have HIP kernels (got \"%s\")",
                 basename_of(desc->fs.glsl_debug_filepath).c_str());
     GPU_REQUIRE(desc->vertex_input_formats_count == 0, nullptr, "GPU_MakeGraphicsPipeline: unsupported (raster): vertex inputs");
-    GPU_REQUIRE(desc->render_pass->desc.color_targets_count == 1, nullptr, "GPU_MakeGraphicsPipeline: the lighting pass has exactly one colour target");
+    GPU_REQUIRE(desc->render_pass->desc.color_targets_count == 1, nullptr, "GPU_MakeGraphicsPipeline: full-screen passes have exactly one colour target");
     GPU_GraphicsPipeline* p = new GPU_GraphicsPipeline();
     p->layout = desc->layout; p->pass = desc->render_pass; p->kernel = k; p->shade_flags = GPUX_Shade_IBL;
     return p;
@@ -836,14 +848,56 @@ static bool check_plane(Slot* s, GPU_Format f, uint32_t w, uint32_t h, const cha
     return true;
 }
 
+static bool check_post_plane(Slot* s, GPU_Format f, uint32_t w, uint32_t h, const char* name, const char* fn) {
+    GPU_REQUIRE(s && s->tex, false, "%s: \"%s\" is not bound", fn, name);
+    GPU_REQUIRE(s->tex->base.format == f && s->tex->base.layer_count == 1 && s->tex->base.depth == 1 && (w == 0 || (s->tex->base.width == w && s->tex->base.height == h)), false,
+                "%s: \"%s\" must be a 2D texture of format %d%s", fn, name, (int)f, w ? " with the pass's size" : "");
+    return true;
+}
+
+// taa_resolve.glsl / final_post_process.glsl drawn as the full-screen triangle (render.cpp:1131-1137, 1181-1187)
+static void record_post(GPU_Graph* g, const DrawParams& dp, uint32_t row0, uint32_t row1, bool explicit_rows, const char* fn) {
+    GPU_RenderPass* rp = g->in_pass;
+    uint32_t W = rp->desc.width, H = rp->desc.height;
+    GPU_REQUIRE_V(rp->targets.size() == 1 && rp->targets[0].texture && rp->targets[0].mip_level == 0, "%s: the pass needs one colour target (mip 0)", fn);
+    TextureImpl* target = (TextureImpl*)rp->targets[0].texture;
+    GPU_REQUIRE_V(target->base.width == W && target->base.height == H && target->base.layer_count == 1, "%s: colour target must be a %ux%u 2D texture", fn, W, H);
+    GPU_DescriptorSet* s = dp.set;
+    if (dp.pipeline->kernel == Kernel_TaaResolve) {
+        GPU_REQUIRE_V(target->base.format == GPU_Format_RGBA16F || target->base.format == GPU_Format_RGBA32F, "%s: TAA target must be RGBA16F/RGBA32F", fn);
+        if (!check_post_plane(named_slot(s, "LIGHTING_RESULT"), GPU_Format_RGBA16F, W, H, "LIGHTING_RESULT", fn)) return;
+        if (!check_post_plane(named_slot(s, "GBUFFER_DEPTH"), GPU_Format_D32F_Or_X8D24UN, W, H, "GBUFFER_DEPTH", fn)) return;
+        if (!check_post_plane(named_slot(s, "GBUFFER_VELOCITY"), GPU_Format_RG16F, W, H, "GBUFFER_VELOCITY", fn)) return;
+        if (!check_post_plane(named_slot(s, "GBUFFER_VELOCITY_PREV"), GPU_Format_RG16F, W, H, "GBUFFER_VELOCITY_PREV", fn)) return;
+        if (!check_post_plane(named_slot(s, "PREV_FRAME_RESULT"), GPU_Format_RGBA16F, 0, 0, "PREV_FRAME_RESULT", fn)) return;
+        GPU_REQUIRE_V(named_slot(s, "PREV_FRAME_RESULT")->tex != target && named_slot(s, "LIGHTING_RESULT")->tex != target,
+                      "%s: the TAA target aliases one of its inputs (the reference ping-pongs taa_output_rt, render.cpp:695-697)", fn);
+    } else {
+        GPU_REQUIRE_V(target->base.format == GPU_Format_RGBA8UN || target->base.format == GPU_Format_BGRA8UN ||
+                      target->base.format == GPU_Format_RGBA16F || target->base.format == GPU_Format_RGBA32F, "%s: unsupported target format %d", fn, (int)target->base.format);
+        if (!check_post_plane(named_slot(s, "TEX0"), GPU_Format_RGBA16F, 0, 0, "TEX0", fn)) return;     // final_post_process.glsl:28 BLOOM_RESULT
+        GPU_REQUIRE_V(named_slot(s, "TEX0")->tex != target, "%s: target aliases TEX0", fn);
+    }
+    Op op;
+    op.kind = Op_Shade;
+    op.gpipe = dp.pipeline; op.set = s; op.pass = rp;
+    op.row0 = explicit_rows ? row0 : 0; op.row1 = explicit_rows ? row1 : H;
+    GPU_REQUIRE_V(op.row0 < op.row1 && op.row1 <= H, "%s: rows [%u,%u) outside the %u-row pass", fn, op.row0, op.row1, H);
+    g->ops.push_back(op);
+}
+
 static void record_shade(GPU_Graph* g, uint32_t row0, uint32_t row1, bool explicit_rows, const char* fn) {
     GPU_REQUIRE_V(g->in_pass && g->bound_draw >= 0, "%s: no draw params bound inside a render pass", fn);
     DrawParams dp = g->draw_params[g->bound_draw];
-    GPU_REQUIRE_V(dp.pipeline->kernel == Kernel_Lighting, "%s: unsupported (raster)", fn);
     GPU_REQUIRE_V(dp.pipeline->pass == g->in_pass, "%s: pipeline was created for a different render pass", fn);
     GPU_REQUIRE_V(dp.set->layout == dp.pipeline->layout, "%s: descriptor set and pipeline use different layouts", fn);
     GPU_RenderPass* rp = g->in_pass;
     uint32_t W = rp->desc.width, H = rp->desc.height;
+    if (dp.pipeline->kernel == Kernel_TaaResolve || dp.pipeline->kernel == Kernel_FinalPost) {
+        record_post(g, dp, row0, row1, explicit_rows, fn);
+        return;
+    }
+    GPU_REQUIRE_V(dp.pipeline->kernel == Kernel_Lighting, "%s: unsupported (raster)", fn);
     GPU_REQUIRE_V(rp->targets.size() == 1 && rp->targets[0].texture, "%s: lighting pass needs one colour target", fn);
     TextureImpl* target = (TextureImpl*)rp->targets[0].texture;
     GPU_REQUIRE_V((target->base.format == GPU_Format_RGBA16F || target->base.format == GPU_Format_RGBA32F) &&
@@ -1132,6 +1186,36 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
         GPU_DescriptorSet* s = op.set;
         GPU_RenderPass* rp = op.pass;
         TextureImpl* target = (TextureImpl*)rp->targets[0].texture;
+        if (op.gpipe->kernel == Kernel_TaaResolve || op.gpipe->kernel == Kernel_FinalPost) {
+            auto tex2d = [](TextureImpl* t, int fmt) { PbrkTex2D r; r.data = t->dev; r.format = fmt; r.width = (int)t->base.width; r.height = (int)t->base.height; return r; };
+            auto out_fmt = [](GPU_Format f) {
+                return f == GPU_Format_RGBA16F ? PBRK_FMT_RGBA16F : (f == GPU_Format_RGBA32F ? PBRK_FMT_RGBA32F : (f == GPU_Format_RGBA8UN ? PBRK_FMT_RGBA8UN : PBRK_FMT_BGRA8UN));
+            };
+            if (op.gpipe->kernel == Kernel_TaaResolve) {
+                PbrkTaaArgs a;
+                a.lighting_result = tex2d(named_slot(s, "LIGHTING_RESULT")->tex, PBRK_FMT_RGBA16F);
+                a.gbuffer_depth = tex2d(named_slot(s, "GBUFFER_DEPTH")->tex, PBRK_FMT_R32F);
+                a.gbuffer_velocity = tex2d(named_slot(s, "GBUFFER_VELOCITY")->tex, PBRK_FMT_RG16F);
+                a.gbuffer_velocity_prev = tex2d(named_slot(s, "GBUFFER_VELOCITY_PREV")->tex, PBRK_FMT_RG16F);
+                a.prev_frame_result = tex2d(named_slot(s, "PREV_FRAME_RESULT")->tex, PBRK_FMT_RGBA16F);
+                a.out = target->dev; a.out_format = out_fmt(target->base.format);
+                a.width = (int)rp->desc.width; a.height = (int)rp->desc.height; a.y0 = (int)op.row0; a.y1 = (int)op.row1;
+                timed(g, "K8.taa_resolve", ev_used, [&] {
+                    int rc = pbrk_taa_resolve(&a, st);
+                    if (rc != PBRK_OK) gpu_fail("K8 launch failed (%d)", rc);
+                });
+            } else {
+                PbrkFinalArgs a;
+                a.src = tex2d(named_slot(s, "TEX0")->tex, PBRK_FMT_RGBA16F);
+                a.out = target->dev; a.out_format = out_fmt(target->base.format);
+                a.width = (int)rp->desc.width; a.height = (int)rp->desc.height; a.y0 = (int)op.row0; a.y1 = (int)op.row1;
+                timed(g, "K9.final_post_process", ev_used, [&] {
+                    int rc = pbrk_final_post_process(&a, st);
+                    if (rc != PBRK_OK) gpu_fail("K9 launch failed (%d)", rc);
+                });
+            }
+            return;
+        }
         PbrkShadeArgs a;
         memset(&a, 0, sizeof a);
         a.width = (int)rp->desc.width; a.height = (int)rp->desc.height;

@@ -79,6 +79,24 @@ class GPUX_IBLConstants(C.Structure):
     _fields_ = [("mip_level", C.c_int32), ("roughness", C.c_float), ("src_lod", C.c_float), ("sample_count", C.c_int32)]
 
 
+class PbrkTex2D(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("format", C.c_int), ("width", C.c_int), ("height", C.c_int)]
+
+
+class PbrkTaaArgs(C.Structure):
+    _fields_ = [("lighting_result", PbrkTex2D), ("gbuffer_depth", PbrkTex2D), ("gbuffer_velocity", PbrkTex2D),
+                ("gbuffer_velocity_prev", PbrkTex2D), ("prev_frame_result", PbrkTex2D), ("out", C.c_void_p),
+                ("out_format", C.c_int), ("width", C.c_int), ("height", C.c_int), ("y0", C.c_int), ("y1", C.c_int)]
+
+
+class PbrkFinalArgs(C.Structure):
+    _fields_ = [("src", PbrkTex2D), ("out", C.c_void_p), ("out_format", C.c_int), ("width", C.c_int), ("height", C.c_int),
+                ("y0", C.c_int), ("y1", C.c_int)]
+
+
+PBRK_FMT_RG16F, PBRK_FMT_RG32F, PBRK_FMT_RGBA16F, PBRK_FMT_RGBA32F, PBRK_FMT_R32F, PBRK_FMT_RGBA8UN, PBRK_FMT_BGRA8UN = 1, 2, 3, 4, 5, 6, 7
+
+
 class PbrkShadeArgs(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("x0", C.c_int), ("x1", C.c_int), ("y0", C.c_int), ("y1", C.c_int),
                 ("base_color", C.c_void_p), ("normal", C.c_void_p), ("orm", C.c_void_p), ("emissive", C.c_void_p),
@@ -161,6 +179,9 @@ PROTOTYPES = {
     "PBR_MakeLightingPass": (VP, [C.POINTER(PBR_GBuffer), C.POINTER(PBR_IBLMaps), U32, U32]), "PBR_DestroyLightingPass": (None, [VP]),
     "PBR_LightingGlobalsBuffer": (BufP, [VP]), "PBR_LightingPipeline": (VP, [VP]),
     "PBR_RecordLightingPass": (None, [VP, VP, C.POINTER(PBR_Globals), U32, U32]),
+    "PBR_MakePostProcess": (VP, [C.POINTER(PBR_GBuffer), U32, U32, C.c_int]), "PBR_DestroyPostProcess": (None, [VP]),
+    "PBR_PostVelocity": (TexP, [VP, U32]), "PBR_PostTaaOutput": (TexP, [VP, U32]), "PBR_PostBackbuffer": (TexP, [VP]),
+    "PBR_RecordTaaResolve": (None, [VP, VP, U32]), "PBR_RecordTaaResolveRows": (None, [VP, VP, U32, U32, U32]), "PBR_RecordFinalPostProcess": (None, [VP, VP, U32]),
     "PBR_MakeLightgrid": (VP, [U32]), "PBR_DestroyLightgrid": (None, [VP]), "PBR_LightgridTexture": (TexP, [VP]),
     "PBR_LightgridSweepDirection": (U32, [VP]), "PBR_RecordLightgridClear": (None, [VP, VP]),
     "PBR_RecordLightgridSweep": (None, [VP, VP]), "PBR_RecordLightgridSweepLines": (None, [VP, VP, U32, U32, U32, U32, U32]),
@@ -172,6 +193,7 @@ PROTOTYPES = {
     "pbrk_host_irradiance_table": (C.c_int, [C.c_int, VP]),
     "pbrk_mip_chain": (C.c_int, [VP, C.c_int, C.c_int, VP]), "pbrk_box_downsample": (C.c_int, [VP, C.c_int, VP, C.c_int, VP]),
     "pbrk_border_build": (C.c_int, [VP, VP, C.c_int, C.c_int, VP]),
+    "pbrk_taa_resolve": (C.c_int, [VP, VP]), "pbrk_final_post_process": (C.c_int, [VP, VP]),
     "pbrk_lightgrid_sweep": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "pbrk_brdf_lut": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, VP]),
     "pbrk_prefilter_copy": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
@@ -206,7 +228,7 @@ def lib():
 
 # ---- conveniences used by tests / bench ------------------------------------------------------
 _FMT_NP = {Format_RGBA32F: (np.float32, 4), Format_RG32F: (np.float32, 2), Format_RG16F: (np.float16, 2),
-           Format_RGBA16F: (np.float16, 4), Format_RGBA8UN: (np.uint8, 4), Format_D32F_Or_X8D24UN: (np.float32, 1),
+           Format_RGBA16F: (np.float16, 4), Format_RGBA8UN: (np.uint8, 4), Format_BGRA8UN: (np.uint8, 4), Format_D32F_Or_X8D24UN: (np.float32, 1),
            Format_R32F: (np.float32, 1)}
 
 

@@ -393,3 +393,27 @@ def synth_lightgrid(size=128, seed=0x5EED00B7, lit=True):
     half = (rng.random((n, n, n)) < 0.002) & ~occ
     g[half, 3] = 0.5
     return g
+
+
+def synth_post_inputs(seed, W, H):
+    """Seeded inputs of the post-process tail: an HDR frame with a few very bright texels, a depth plane, smooth
+    sub-pixel velocities with a patch of large motion (history rejection) and a strip that reprojects off-screen."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    lighting = np.zeros((H, W, 4), np.float16)
+    base = 0.4 + 0.3 * np.sin(xx * 0.37) * np.cos(yy * 0.23)
+    lighting[..., :3] = (base[..., None] * np.array([1.0, 0.8, 0.6]) + rng.random((H, W, 3)) * 0.2).astype(np.float16)
+    hot = rng.random((H, W)) < 0.01
+    lighting[hot, :3] = (rng.random((int(hot.sum()), 3)) * 300.0).astype(np.float16)
+    lighting[..., 3] = 1.0
+    history = lighting.copy()
+    history[..., :3] = (history[..., :3].astype(np.float32) * (0.7 + 0.6 * rng.random((H, W, 3)))).astype(np.float16)
+    depth = (0.9980 + 0.0015 * rng.random((H, W))).astype(np.float32)
+    vel = np.zeros((H, W, 2), np.float16)
+    vel[..., 0] = (0.004 * np.sin(yy * 0.11) + 0.0007).astype(np.float16)
+    vel[..., 1] = (0.003 * np.cos(xx * 0.07)).astype(np.float16)
+    vel[:, : max(2, W // 16), 0] = 0.5                      # reprojects to uv.x < 0: history rejected (:272-275)
+    vel_prev = vel.copy()
+    patch = (slice(H // 3, H // 2), slice(W // 3, W // 2))
+    vel_prev[patch] = (vel_prev[patch].astype(np.float32) + 0.01).astype(np.float16)   # velocity-based rejection (:269-270)
+    return lighting, depth, vel, vel_prev, history
