@@ -91,19 +91,45 @@ __device__ __forceinline__ CrAxis catmull_rom_axis(float uv, float ts) {
     return r;
 }
 
+__device__ __forceinline__ uint2 pack_half4(float r0, float r1, float r2) {
+    uint2 v;
+    v.x = (unsigned)__half_as_ushort(__float2half_rn(r0)) | ((unsigned)__half_as_ushort(__float2half_rn(r1)) << 16);
+    v.y = (unsigned)__half_as_ushort(__float2half_rn(r2)) | (0x3c00u << 16);
+    return v;
+}
+
+// buffer-addressed texel fetches: one 32-bit offset per load instead of a 64-bit address (textures are < 2 GiB, checked on the host)
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tex_rsrc(const PbrkTex2D& t, int texel_bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)t.data, 0, t.width * t.height * texel_bytes, 0x00020000);
+}
+__device__ __forceinline__ Rgba fetch_rgba16f(__amdgpu_buffer_rsrc_t rs, int w, int i, int j) {
+    u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rs, (j * w + i) * 8, 0, 0);
+    return Rgba{h2f(v.x & 0xffff), h2f(v.x >> 16), h2f(v.y & 0xffff), h2f(v.y >> 16)};
+}
+__device__ __forceinline__ float2 fetch_rg16f(__amdgpu_buffer_rsrc_t rs, int w, int i, int j) {
+    unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, (j * w + i) * 4, 0, 0);
+    return make_float2(h2f(v & 0xffff), h2f(v >> 16));
+}
+
+// kCentreExact (frames up to 8192^2): every tap the shader aims at a texel centre -- the 3x3 neighbourhood, depth, the
+// velocity tap and the outer Catmull-Rom taps -- is one texel fetch, and the outer taps need neither their division by the
+// texture size nor the bilinear split (their texel is floor(sp - 0.5) - 1 / + 2).  Otherwise every tap goes through the sampler.
 template <bool kCentreExact, bool kHalfOut>
 __global__ __launch_bounds__(256) void k_taa_resolve(PbrkTaaArgs A) {
     const int px = blockIdx.x * 64 + (threadIdx.x & 63);
     const int py = A.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (px >= A.width || py >= A.y1) return;
     const PbrkTex2D& LR = A.lighting_result;
-    const float tsx = (float)LR.width, tsy = (float)LR.height;                 // :189
+    const PbrkTex2D& HI = A.prev_frame_result;
+    const int W = LR.width, H = LR.height;
+    const __amdgpu_buffer_rsrc_t rs_lr = tex_rsrc(LR, 8), rs_hi = tex_rsrc(HI, 8), rs_v = tex_rsrc(A.gbuffer_velocity, 4), rs_pv = tex_rsrc(A.gbuffer_velocity_prev, 4);
+    const float tsx = (float)W, tsy = (float)H;                                 // :189
     const float psx = 1.0f / tsx, psy = 1.0f / tsy;                             // :190
     const float uvx = ((float)px + 0.5f) * psx, uvy = ((float)py + 0.5f) * psy; // :192
 
     float tot[3] = {0, 0, 0}, wsum = 0.0f, m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
     float closest_depth = 10000.0f, cdu = 0.0f, cdv = 0.0f;
-    int cdi = 0, cdj = 0;
     const float depth = kCentreExact ? ((const float*)A.gbuffer_depth.data)[(size_t)py * A.gbuffer_depth.width + px]
                                      : sample_r32f(A.gbuffer_depth, uvx, uvy);  // :221 (same tap nine times)
 #pragma unroll
@@ -111,8 +137,7 @@ __global__ __launch_bounds__(256) void k_taa_resolve(PbrkTaaArgs A) {
 #pragma unroll
         for (int y = -1; y <= 1; ++y) {
             float su = uvx + (float)x * psx, sv = uvy + (float)y * psy;
-            Rgba nb = kCentreExact ? texel_rgba16f(LR, clampi(px + x, 0, LR.width - 1), clampi(py + y, 0, LR.height - 1))
-                                   : sample_rgba16f(LR, su, sv);
+            Rgba nb = kCentreExact ? fetch_rgba16f(rs_lr, W, clampi(px + x, 0, W - 1), clampi(py + y, 0, H - 1)) : sample_rgba16f(LR, su, sv);
             float w = mitchell_netravali(sqrtf((float)x * (float)x + (float)y * (float)y));
             float n[3] = {nb.x, nb.y, nb.z};
 #pragma unroll
@@ -122,40 +147,64 @@ __global__ __launch_bounds__(256) void k_taa_resolve(PbrkTaaArgs A) {
                 m2[k] = m2[k] + n[k] * n[k];
             }
             wsum = wsum + w;
-            if (depth < closest_depth) { closest_depth = depth; cdu = su; cdv = sv; cdi = px + x; cdj = py + y; }
+            if (depth < closest_depth) { closest_depth = depth; cdu = su; cdv = sv; }   // :222-225: only the first tap (-1,-1) can win
         }
     float src[3] = {tot[0] / wsum, tot[1] / wsum, tot[2] / wsum};               // :228
     float2 vel;
-    if (kCentreExact && closest_depth < 10000.0f)
-        vel = texel_rg16f(A.gbuffer_velocity, clampi(cdi, 0, A.gbuffer_velocity.width - 1), clampi(cdj, 0, A.gbuffer_velocity.height - 1));
-    else
-        vel = sample_rg16f(A.gbuffer_velocity, cdu, cdv);                       // :230
+    if (kCentreExact && closest_depth < 10000.0f) vel = fetch_rg16f(rs_v, W, clampi(px - 1, 0, W - 1), clampi(py - 1, 0, H - 1));
+    else vel = sample_rg16f(A.gbuffer_velocity, cdu, cdv);                      // :230
     const float ru = uvx - vel.x * 0.5f, rv = uvy - vel.y * 0.5f;               // :231
-    const float2 pvel = sample_rg16f(A.gbuffer_velocity_prev, ru, rv);          // :232
+    float2 pvel;                                                                // :232
+    {
+        int i0, i1, j0, j1; float a, b;
+        split_axis(ru, W, i0, i1, a); split_axis(rv, H, j0, j1, b);
+        float2 t00 = fetch_rg16f(rs_pv, W, i0, j0), t10 = fetch_rg16f(rs_pv, W, i1, j0), t01 = fetch_rg16f(rs_pv, W, i0, j1), t11 = fetch_rg16f(rs_pv, W, i1, j1);
+        pvel = make_float2(lerpx(lerpx(t00.x, t10.x, a), lerpx(t01.x, t11.x, a), b), lerpx(lerpx(t00.y, t10.y, a), lerpx(t01.y, t11.y, a), b));
+    }
 
-    // :234 history, 9 bilinear taps in the shader's order; with kCentreExact the p0 / p3 taps are single texels
-    const PbrkTex2D& HI = A.prev_frame_result;
-    CrAxis cx = catmull_rom_axis(ru, tsx), cy = catmull_rom_axis(rv, tsy);
+    // :234 history, 9 bilinear taps in the shader's order
     float prev[3] = {0, 0, 0};
     {
-        const float pxs[3] = {cx.p0, cx.p12, cx.p3}, wxs[3] = {cx.w0, cx.w12, cx.w3};
-        const float pys[3] = {cy.p0, cy.p12, cy.p3}, wys[3] = {cy.w0, cy.w12, cy.w3};
-        int ci0[3], ci1[3], cj0[3], cj1[3]; float ca[3], cb[3];
+        const int HW = HI.width, HH = HI.height;
+        float wxs[3], wys[3], ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
+        int ci0[3], ci1[3], cj0[3], cj1[3];
+        const float uvs[2] = {ru, rv}, tss[2] = {tsx, tsy};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { split_axis(pxs[k], HI.width, ci0[k], ci1[k], ca[k]); split_axis(pys[k], HI.height, cj0[k], cj1[k], cb[k]); }
+        for (int axis = 0; axis < 2; ++axis) {                                  // :139-167
+            int* i0 = axis ? cj0 : ci0; int* i1 = axis ? cj1 : ci1; float* wt = axis ? wys : wxs; float* frac = axis ? cb : ca;
+            const int extent = axis ? HH : HW;
+            float sp = uvs[axis] * tss[axis];
+            float fl = floorf(sp - 0.5f);
+            float tp1 = fl + 0.5f;
+            float f = sp - tp1;
+            wt[0] = f * (-0.5f + f * (1.0f - 0.5f * f));
+            float w1 = 1.0f + f * f * (-2.5f + 1.5f * f);
+            float w2 = f * (0.5f + f * (2.0f - 1.5f * f));
+            wt[2] = f * f * (-0.5f + 0.5f * f);
+            wt[1] = w1 + w2;
+            float offset12 = w2 / (w1 + w2);
+            split_axis((tp1 + offset12) / tss[axis], extent, i0[1], i1[1], frac[1]);
+            if (kCentreExact) {
+                int t = (int)fl;
+                i0[0] = i1[0] = clampi(t - 1, 0, extent - 1); i0[2] = i1[2] = clampi(t + 2, 0, extent - 1);
+            } else {
+                split_axis((tp1 - 1.0f) / tss[axis], extent, i0[0], i1[0], frac[0]);
+                split_axis((tp1 + 2.0f) / tss[axis], extent, i0[2], i1[2], frac[2]);
+            }
+        }
 #pragma unroll
         for (int row = 0; row < 3; ++row)
 #pragma unroll
             for (int col = 0; col < 3; ++col) {
                 const bool x_exact = kCentreExact && col != 1, y_exact = kCentreExact && row != 1;
-                Rgba t00 = texel_rgba16f(HI, ci0[col], cj0[row]);
-                Rgba top = t00, bot;
-                if (!x_exact) { Rgba t10 = texel_rgba16f(HI, ci1[col], cj0[row]); top = Rgba{lerpx(t00.x, t10.x, ca[col]), lerpx(t00.y, t10.y, ca[col]), lerpx(t00.z, t10.z, ca[col]), 0.f}; }
+                Rgba t00 = fetch_rgba16f(rs_hi, HW, ci0[col], cj0[row]);
+                Rgba top = t00;
+                if (!x_exact) { Rgba t10 = fetch_rgba16f(rs_hi, HW, ci1[col], cj0[row]); top = Rgba{lerpx(t00.x, t10.x, ca[col]), lerpx(t00.y, t10.y, ca[col]), lerpx(t00.z, t10.z, ca[col]), 0.f}; }
                 Rgba s = top;
                 if (!y_exact) {
-                    Rgba t01 = texel_rgba16f(HI, ci0[col], cj1[row]);
-                    bot = t01;
-                    if (!x_exact) { Rgba t11 = texel_rgba16f(HI, ci1[col], cj1[row]); bot = Rgba{lerpx(t01.x, t11.x, ca[col]), lerpx(t01.y, t11.y, ca[col]), lerpx(t01.z, t11.z, ca[col]), 0.f}; }
+                    Rgba t01 = fetch_rgba16f(rs_hi, HW, ci0[col], cj1[row]);
+                    Rgba bot = t01;
+                    if (!x_exact) { Rgba t11 = fetch_rgba16f(rs_hi, HW, ci1[col], cj1[row]); bot = Rgba{lerpx(t01.x, t11.x, ca[col]), lerpx(t01.y, t11.y, ca[col]), lerpx(t01.z, t11.z, ca[col]), 0.f}; }
                     s = Rgba{lerpx(top.x, bot.x, cb[row]), lerpx(top.y, bot.y, cb[row]), lerpx(top.z, bot.z, cb[row]), 0.f};
                 }
                 prev[0] = prev[0] + (s.x * wxs[col]) * wys[row];
@@ -178,14 +227,8 @@ __global__ __launch_bounds__(256) void k_taa_resolve(PbrkTaaArgs A) {
     const float den = fmaxf(wB + wA, 0.00001f);
     float r0 = (src[0] * wB + prev[0] * wA) / den, r1 = (src[1] * wB + prev[1] * wA) / den, r2 = (src[2] * wB + prev[2] * wA) / den;   // :277
     const size_t o = (size_t)py * A.width + px;
-    if (kHalfOut) {
-        uint2 v;
-        v.x = (unsigned)__half_as_ushort(__float2half_rn(r0)) | ((unsigned)__half_as_ushort(__float2half_rn(r1)) << 16);
-        v.y = (unsigned)__half_as_ushort(__float2half_rn(r2)) | (0x3c00u << 16);
-        ((uint2*)A.out)[o] = v;
-    } else {
-        ((float4*)A.out)[o] = make_float4(r0, r1, r2, 1.0f);                    // :290
-    }
+    if (kHalfOut) ((uint2*)A.out)[o] = pack_half4(r0, r1, r2);
+    else ((float4*)A.out)[o] = make_float4(r0, r1, r2, 1.0f);                   // :290
 }
 
 __device__ __forceinline__ float aces_approx(float v) {                   // final_post_process.glsl:2-10
@@ -197,27 +240,65 @@ __device__ __forceinline__ unsigned to_unorm8(float v) {                   // re
     return (unsigned)__float2int_rn(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f);
 }
 
+// pow(x, 1/2.2) for x in [0,1] through the hardware log2 / exp2 (1 ulp each): relative error < 1e-6, far inside the
+// 8-bit target's step and the 1e-5 the float targets are checked to; libm's powf costs ~10x more instructions.
+__device__ __forceinline__ float pow_gamma(float x) {
+    return __builtin_amdgcn_exp2f((1.0f / 2.2f) * __builtin_amdgcn_logf(x));
+}
+__device__ __forceinline__ void tone_map(const Rgba& s, float& r0, float& r1, float& r2) {     // :32-33
+    r0 = pow_gamma(aces_approx(2.0f * s.x)); r1 = pow_gamma(aces_approx(2.0f * s.y)); r2 = pow_gamma(aces_approx(2.0f * s.z));
+}
+template <int kOutFmt> __device__ __forceinline__ unsigned pack8(float r0, float r1, float r2) {
+    return kOutFmt == PBRK_FMT_RGBA8UN ? (to_unorm8(r0) | (to_unorm8(r1) << 8) | (to_unorm8(r2) << 16) | 0xff000000u)
+                                       : (to_unorm8(r2) | (to_unorm8(r1) << 8) | (to_unorm8(r0) << 16) | 0xff000000u);
+}
+
+// general form: any source size (bilinear), one pixel per thread
 template <int kOutFmt>
 __global__ __launch_bounds__(256) void k_final_post_process(PbrkFinalArgs A) {
     const int px = blockIdx.x * 64 + (threadIdx.x & 63);
     const int py = A.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (px >= A.width || py >= A.y1) return;
-    Rgba s;
-    if (A.src.width == A.width && A.src.height == A.height && A.width <= 8192 && A.height <= 8192)
-        s = texel_rgba16f(A.src, px, py);                                       // centre tap of an equal-size source
-    else
-        s = sample_rgba16f(A.src, ((float)px + 0.5f) / (float)A.width, ((float)py + 0.5f) / (float)A.height);
-    const float g = 1.0f / 2.2f;
-    float r0 = powf(aces_approx(2.0f * s.x), g), r1 = powf(aces_approx(2.0f * s.y), g), r2 = powf(aces_approx(2.0f * s.z), g);   // :32-33
+    Rgba s = sample_rgba16f(A.src, ((float)px + 0.5f) / (float)A.width, ((float)py + 0.5f) / (float)A.height);
+    float r0, r1, r2;
+    tone_map(s, r0, r1, r2);
     const size_t o = (size_t)py * A.width + px;
-    if (kOutFmt == PBRK_FMT_RGBA8UN) ((unsigned*)A.out)[o] = to_unorm8(r0) | (to_unorm8(r1) << 8) | (to_unorm8(r2) << 16) | 0xff000000u;
-    else if (kOutFmt == PBRK_FMT_BGRA8UN) ((unsigned*)A.out)[o] = to_unorm8(r2) | (to_unorm8(r1) << 8) | (to_unorm8(r0) << 16) | 0xff000000u;
-    else if (kOutFmt == PBRK_FMT_RGBA16F) {
-        uint2 v;
-        v.x = (unsigned)__half_as_ushort(__float2half_rn(r0)) | ((unsigned)__half_as_ushort(__float2half_rn(r1)) << 16);
-        v.y = (unsigned)__half_as_ushort(__float2half_rn(r2)) | (0x3c00u << 16);
-        ((uint2*)A.out)[o] = v;
-    } else ((float4*)A.out)[o] = make_float4(r0, r1, r2, 1.0f);
+    if (kOutFmt == PBRK_FMT_RGBA8UN || kOutFmt == PBRK_FMT_BGRA8UN) ((unsigned*)A.out)[o] = pack8<kOutFmt>(r0, r1, r2);
+    else if (kOutFmt == PBRK_FMT_RGBA16F) ((uint2*)A.out)[o] = pack_half4(r0, r1, r2);
+    else ((float4*)A.out)[o] = make_float4(r0, r1, r2, 1.0f);
+}
+
+// the reference's case: source and target have one size, every tap is a texel centre -> a streaming map, 4 pixels
+// (32 B in, 16 B out for the 8-bit targets) per thread; width % 4 == 0
+template <int kOutFmt>
+__global__ __launch_bounds__(256) void k_final_post_process_stream(PbrkFinalArgs A) {
+    const int quads_per_row = A.width >> 2;
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t nq = (size_t)quads_per_row * (A.y1 - A.y0);
+    if (q >= nq) return;
+    const size_t first = (size_t)A.y0 * A.width + q * 4;                        // rows are contiguous: a flat range of pixels
+    const uint4* src = (const uint4*)((const uint2*)A.src.data + first);
+    uint4 v0 = src[0], v1 = src[1];
+    const unsigned raw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    float r[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        Rgba s{h2f(raw[2 * k] & 0xffff), h2f(raw[2 * k] >> 16), h2f(raw[2 * k + 1] & 0xffff), 1.0f};
+        tone_map(s, r[k][0], r[k][1], r[k][2]);
+    }
+    if (kOutFmt == PBRK_FMT_RGBA8UN || kOutFmt == PBRK_FMT_BGRA8UN) {
+        ((uint4*)((unsigned*)A.out + first))[0] = make_uint4(pack8<kOutFmt>(r[0][0], r[0][1], r[0][2]), pack8<kOutFmt>(r[1][0], r[1][1], r[1][2]),
+                                                             pack8<kOutFmt>(r[2][0], r[2][1], r[2][2]), pack8<kOutFmt>(r[3][0], r[3][1], r[3][2]));
+    } else if (kOutFmt == PBRK_FMT_RGBA16F) {
+        uint2 a = pack_half4(r[0][0], r[0][1], r[0][2]), b = pack_half4(r[1][0], r[1][1], r[1][2]);
+        uint2 c = pack_half4(r[2][0], r[2][1], r[2][2]), d = pack_half4(r[3][0], r[3][1], r[3][2]);
+        uint4* o = (uint4*)((uint2*)A.out + first);
+        o[0] = make_uint4(a.x, a.y, b.x, b.y); o[1] = make_uint4(c.x, c.y, d.x, d.y);
+    } else {
+        float4* o = (float4*)A.out + first;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = make_float4(r[k][0], r[k][1], r[k][2], 1.0f);
+    }
 }
 
 bool tex_ok(const PbrkTex2D& t, int fmt) { return t.data && t.format == fmt && t.width > 0 && t.height > 0; }
@@ -232,6 +313,7 @@ extern "C" int pbrk_taa_resolve(const PbrkTaaArgs* a, void* stream) {
     const PbrkTex2D* same[4] = {&a->lighting_result, &a->gbuffer_depth, &a->gbuffer_velocity, &a->gbuffer_velocity_prev};
     for (int k = 0; k < 4; ++k) if (same[k]->width != a->width || same[k]->height != a->height) return PBRK_E_ARG;
     if (a->out == a->prev_frame_result.data || a->out == a->lighting_result.data) return PBRK_E_ARG;
+    if ((long long)a->width * a->height > (1ll << 27) || (long long)a->prev_frame_result.width * a->prev_frame_result.height > (1ll << 27)) return PBRK_E_ARG;   // 32-bit byte offsets
     const bool centre = a->width <= 8192 && a->height <= 8192;
     const bool half = a->out_format == PBRK_FMT_RGBA16F;
     dim3 grid((a->width + 63) / 64, (a->y1 - a->y0 + 3) / 4), block(256);
@@ -247,14 +329,19 @@ extern "C" int pbrk_final_post_process(const PbrkFinalArgs* a, void* stream) {
     if (!a || !a->out || a->width < 1 || a->height < 1 || a->y0 < 0 || a->y0 >= a->y1 || a->y1 > a->height) return PBRK_E_ARG;
     if (!tex_ok(a->src, PBRK_FMT_RGBA16F)) return PBRK_E_FORMAT;
     if (a->out == a->src.data) return PBRK_E_ARG;
-    dim3 grid((a->width + 63) / 64, (a->y1 - a->y0 + 3) / 4), block(256);
     hipStream_t st = (hipStream_t)stream;
+    const bool stream_map = a->src.width == a->width && a->src.height == a->height && a->width <= 8192 && a->height <= 8192 && (a->width & 3) == 0;
+    dim3 block(256);
+    dim3 grid = stream_map ? dim3((unsigned)((((size_t)(a->width >> 2) * (a->y1 - a->y0)) + 255) / 256)) : dim3((a->width + 63) / 64, (a->y1 - a->y0 + 3) / 4);
+#define PBRK_FINAL_LAUNCH(F) do { if (stream_map) hipLaunchKernelGGL((k_final_post_process_stream<F>), grid, block, 0, st, *a); \
+                                  else hipLaunchKernelGGL((k_final_post_process<F>), grid, block, 0, st, *a); } while (0)
     switch (a->out_format) {
-    case PBRK_FMT_RGBA8UN: hipLaunchKernelGGL((k_final_post_process<PBRK_FMT_RGBA8UN>), grid, block, 0, st, *a); break;
-    case PBRK_FMT_BGRA8UN: hipLaunchKernelGGL((k_final_post_process<PBRK_FMT_BGRA8UN>), grid, block, 0, st, *a); break;
-    case PBRK_FMT_RGBA16F: hipLaunchKernelGGL((k_final_post_process<PBRK_FMT_RGBA16F>), grid, block, 0, st, *a); break;
-    case PBRK_FMT_RGBA32F: hipLaunchKernelGGL((k_final_post_process<PBRK_FMT_RGBA32F>), grid, block, 0, st, *a); break;
+    case PBRK_FMT_RGBA8UN: PBRK_FINAL_LAUNCH(PBRK_FMT_RGBA8UN); break;
+    case PBRK_FMT_BGRA8UN: PBRK_FINAL_LAUNCH(PBRK_FMT_BGRA8UN); break;
+    case PBRK_FMT_RGBA16F: PBRK_FINAL_LAUNCH(PBRK_FMT_RGBA16F); break;
+    case PBRK_FMT_RGBA32F: PBRK_FINAL_LAUNCH(PBRK_FMT_RGBA32F); break;
     default: return PBRK_E_FORMAT;
     }
+#undef PBRK_FINAL_LAUNCH
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
