@@ -288,9 +288,78 @@ def synth_gbuffer_spheres(width=1920, height=1080, cam_pos=(0.0, -9.0, 0.0), ori
                 cam_pos=np.asarray(cam_pos, np.float64), ori_q=ori_q)
 
 
-def synth_gbuffer_temple(width=7680, height=4320, seed=0x5EED0005, cam_pos=(0.0, -30.0, 6.0), ori_q=None):
+def _temple_block(args):
+    width, height, seed, cam_pos, ori_q, y0, y1 = args
+    cam = camera_matrices(np.asarray(cam_pos, dtype=np.float64), ori_q, aspect=width / height)
+    n = y1 - y0
+    base = np.zeros((n, width, 4), np.uint8); nrm = np.zeros((n, width, 4), np.uint8)
+    orm = np.zeros((n, width, 4), np.uint8); emi = np.zeros((n, width, 4), np.uint8)
+    depth = np.ones((n, width), np.float32)
+    o = np.asarray(cam_pos, dtype=np.float64)
+    wfc = cam["world_from_clip"]
+    xs = (np.arange(width) + 0.5) / width * 2 - 1
+    col_ang = np.arange(32) * (2 * np.pi / 32)
+    col_c = np.stack([18 * np.cos(col_ang), 18 * np.sin(col_ang)], axis=-1)
+    ys = (np.arange(y0, y1) + 0.5) / height * 2 - 1
+    X, Y = np.meshgrid(xs, ys, indexing="xy")
+    p = np.stack([X, Y, np.full_like(X, 0.5), np.ones_like(X)], axis=-1) @ wfc.T
+    rd = p[..., :3] / p[..., 3:4] - o
+    rd /= np.linalg.norm(rd, axis=-1, keepdims=True)
+    tb = np.full(X.shape, np.inf)
+    N = np.zeros(X.shape + (3,))
+    # ground
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = -o[2] / rd[..., 2]
+    hit = (rd[..., 2] < 0) & (t > 0) & (t < 400)
+    tb = np.where(hit, t, tb)
+    N[hit] = (0, 0, 1)
+    # dome (sphere radius 60 centred at origin, seen from inside, only z>0 part)
+    b = rd @ o
+    disc = b * b - (o @ o - 60.0 ** 2)
+    t = -b + np.sqrt(np.maximum(disc, 0))
+    P = o + rd * t[..., None]
+    hit = (disc > 0) & (t > 0) & (P[..., 2] > 0) & (t < tb)
+    tb = np.where(hit, t, tb)
+    N = np.where(hit[..., None], -P / 60.0, N)
+    # columns (vertical cylinders radius 1.2, height 14)
+    for c in col_c:
+        oc = o[:2] - c
+        a = (rd[..., :2] ** 2).sum(-1)
+        bb = rd[..., :2] @ oc
+        cc = oc @ oc - 1.2 ** 2
+        disc = bb * bb - a * cc
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (-bb - np.sqrt(np.maximum(disc, 0))) / a
+        P = o + rd * t[..., None]
+        hit = (disc > 0) & (t > 0) & (t < tb) & (P[..., 2] > 0) & (P[..., 2] < 14)
+        tb = np.where(hit, t, tb)
+        n = np.concatenate([(P[..., :2] - c) / 1.2, np.zeros_like(P[..., :1])], axis=-1)
+        N = np.where(hit[..., None], n, N)
+    hit = np.isfinite(tb)
+    P = o + rd * np.where(hit, tb, 0)[..., None]
+    clip = np.concatenate([P, np.ones_like(P[..., :1])], axis=-1) @ cam["clip_from_world"].T
+    z = (clip[..., 2] / clip[..., 3]).astype(np.float32)
+    depth[:] = np.where(hit, z, 1.0)
+    n1 = value_noise3(P * 0.7 + 3.0, seed)
+    n2 = value_noise3(P * 2.9 + 11.0, seed ^ 0xABCDEF)
+    n3 = value_noise3(P * 0.23 + 7.0, seed ^ 0x13579B)
+    bc = np.stack([0.35 + 0.6 * n1, 0.3 + 0.55 * n2, 0.25 + 0.5 * n3], axis=-1)
+    base[:, :, :3] = np.where(hit[..., None], _encode_unorm8(bc), 0)
+    base[:, :, 3] = np.where(hit, 255, 0)
+    nrm[:, :, :3] = np.where(hit[..., None], _encode_unorm8(N * 0.5 + 0.5), 0)
+    nrm[:, :, 3] = np.where(hit, 255, 0)
+    o3 = np.stack([np.ones_like(n1), 0.08 + 0.9 * n2, (n3 > 0.6).astype(np.float64), np.ones_like(n1)], axis=-1)
+    orm[:] = np.where(hit[..., None], _encode_unorm8(o3), 0)
+    em = (n1 * 7919.0 % 1.0 < 0.02) & hit
+    emi[:, :, :3] = np.where(em[..., None], _encode_unorm8(np.stack([n2, 0.5 * n3, 0.2 * n1], axis=-1)), 0)
+    return y0, y1, base, nrm, orm, emi, depth
+
+
+def synth_gbuffer_temple(width=7680, height=4320, seed=0x5EED0005, cam_pos=(0.0, -30.0, 6.0), ori_q=None, rows=None, workers=1):
     """C5: ground plane z=0 + ring of 32 columns + dome, per-pixel material from value noise,
-    2% emissive pixels.  Analytic ray casting in float64, evaluated row-block-wise."""
+    2% emissive pixels.  Analytic ray casting in float64, evaluated row-block-wise.
+    rows=(y0, y1) fills only that band of the full-size planes (the rest stays sky: depth 1, zero planes) -- what one
+    rank of a screen-band split needs; workers > 1 spreads the row blocks over forked processes (same result)."""
     ori_q = DEFAULT_ORI if ori_q is None else ori_q
     cam = camera_matrices(np.asarray(cam_pos, dtype=np.float64), ori_q, aspect=width / height)
     base = np.zeros((height, width, 4), np.uint8)
@@ -298,66 +367,17 @@ def synth_gbuffer_temple(width=7680, height=4320, seed=0x5EED0005, cam_pos=(0.0,
     orm = np.zeros((height, width, 4), np.uint8)
     emi = np.zeros((height, width, 4), np.uint8)
     depth = np.ones((height, width), np.float32)
-    o = np.asarray(cam_pos, dtype=np.float64)
-    wfc = cam["world_from_clip"]
-    xs = (np.arange(width) + 0.5) / width * 2 - 1
-    col_ang = np.arange(32) * (2 * np.pi / 32)
-    col_c = np.stack([18 * np.cos(col_ang), 18 * np.sin(col_ang)], axis=-1)
+    r0, r1 = rows if rows is not None else (0, height)
     blk = 135
-    for y0 in range(0, height, blk):
-        y1 = min(height, y0 + blk)
-        ys = (np.arange(y0, y1) + 0.5) / height * 2 - 1
-        X, Y = np.meshgrid(xs, ys, indexing="xy")
-        p = np.stack([X, Y, np.full_like(X, 0.5), np.ones_like(X)], axis=-1) @ wfc.T
-        rd = p[..., :3] / p[..., 3:4] - o
-        rd /= np.linalg.norm(rd, axis=-1, keepdims=True)
-        tb = np.full(X.shape, np.inf)
-        N = np.zeros(X.shape + (3,))
-        # ground
-        with np.errstate(divide="ignore", invalid="ignore"):
-            t = -o[2] / rd[..., 2]
-        hit = (rd[..., 2] < 0) & (t > 0) & (t < 400)
-        tb = np.where(hit, t, tb)
-        N[hit] = (0, 0, 1)
-        # dome (sphere radius 60 centred at origin, seen from inside, only z>0 part)
-        b = rd @ o
-        disc = b * b - (o @ o - 60.0 ** 2)
-        t = -b + np.sqrt(np.maximum(disc, 0))
-        P = o + rd * t[..., None]
-        hit = (disc > 0) & (t > 0) & (P[..., 2] > 0) & (t < tb)
-        tb = np.where(hit, t, tb)
-        N = np.where(hit[..., None], -P / 60.0, N)
-        # columns (vertical cylinders radius 1.2, height 14)
-        for c in col_c:
-            oc = o[:2] - c
-            a = (rd[..., :2] ** 2).sum(-1)
-            bb = rd[..., :2] @ oc
-            cc = oc @ oc - 1.2 ** 2
-            disc = bb * bb - a * cc
-            with np.errstate(divide="ignore", invalid="ignore"):
-                t = (-bb - np.sqrt(np.maximum(disc, 0))) / a
-            P = o + rd * t[..., None]
-            hit = (disc > 0) & (t > 0) & (t < tb) & (P[..., 2] > 0) & (P[..., 2] < 14)
-            tb = np.where(hit, t, tb)
-            n = np.concatenate([(P[..., :2] - c) / 1.2, np.zeros_like(P[..., :1])], axis=-1)
-            N = np.where(hit[..., None], n, N)
-        hit = np.isfinite(tb)
-        P = o + rd * np.where(hit, tb, 0)[..., None]
-        clip = np.concatenate([P, np.ones_like(P[..., :1])], axis=-1) @ cam["clip_from_world"].T
-        z = (clip[..., 2] / clip[..., 3]).astype(np.float32)
-        depth[y0:y1] = np.where(hit, z, 1.0)
-        n1 = value_noise3(P * 0.7 + 3.0, seed)
-        n2 = value_noise3(P * 2.9 + 11.0, seed ^ 0xABCDEF)
-        n3 = value_noise3(P * 0.23 + 7.0, seed ^ 0x13579B)
-        bc = np.stack([0.35 + 0.6 * n1, 0.3 + 0.55 * n2, 0.25 + 0.5 * n3], axis=-1)
-        base[y0:y1, :, :3] = np.where(hit[..., None], _encode_unorm8(bc), 0)
-        base[y0:y1, :, 3] = np.where(hit, 255, 0)
-        nrm[y0:y1, :, :3] = np.where(hit[..., None], _encode_unorm8(N * 0.5 + 0.5), 0)
-        nrm[y0:y1, :, 3] = np.where(hit, 255, 0)
-        o3 = np.stack([np.ones_like(n1), 0.08 + 0.9 * n2, (n3 > 0.6).astype(np.float64), np.ones_like(n1)], axis=-1)
-        orm[y0:y1] = np.where(hit[..., None], _encode_unorm8(o3), 0)
-        em = (n1 * 7919.0 % 1.0 < 0.02) & hit
-        emi[y0:y1, :, :3] = np.where(em[..., None], _encode_unorm8(np.stack([n2, 0.5 * n3, 0.2 * n1], axis=-1)), 0)
+    jobs = [(width, height, seed, tuple(cam_pos), ori_q, y0, min(r1, y0 + blk)) for y0 in range(r0, r1, blk)]
+    if workers > 1 and len(jobs) > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+            parts = pool.map(_temple_block, jobs)
+    else:
+        parts = [_temple_block(j) for j in jobs]
+    for y0, y1, b, n, o_, e, d in parts:
+        base[y0:y1], nrm[y0:y1], orm[y0:y1], emi[y0:y1], depth[y0:y1] = b, n, o_, e, d
     return dict(base=base, normal=nrm, orm=orm, emissive=emi, depth=depth, camera=cam,
                 cam_pos=np.asarray(cam_pos, np.float64), ori_q=ori_q)
 
