@@ -469,10 +469,10 @@ def shade_c5_bench(L, pbrhip, env_tex, rank, world, backend, torch, dist, frames
 
     band = lambda r: out_mem[(H * r // world) * W * 4: (H * (r + 1) // world) * W * 4]
 
-    def frame():
+    def frame(gather=True):
         L.PBR_RecordLightingPass(lp, g, C.byref(glob), r0, r1)
         L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
-        if world > 1:
+        if world > 1 and gather:
             ops, staged = [], []
             if rank == 0:
                 for r in range(1, world):
@@ -502,10 +502,15 @@ def shade_c5_bench(L, pbrhip, env_tex, rank, world, backend, torch, dist, frames
         k_ms += [L.GPUX_GraphTimedOpMs(g, i) for i in range(L.GPUX_GraphTimedOpCount(g)) if L.GPUX_GraphTimedOpName(g, i).decode() == "K5.shade"]
     sync()
     elapsed = time.perf_counter() - t0
+    t0 = time.perf_counter()                                                    # the same frames without the exchange (bands stay where they are shaded)
+    for _ in range(frames):
+        frame(gather=False)
+    sync()
+    elapsed_local = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        tt = torch.tensor([elapsed, elapsed_local], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, elapsed_local = float(tt[0].item()), float(tt[1].item())
     if rank == 0:
         k = float(np.mean(k_ms)) if k_ms else float("nan")
         byt = 28.0 * W * (r1 - r0)
@@ -513,6 +518,8 @@ def shade_c5_bench(L, pbrhip, env_tex, rank, world, backend, torch, dist, frames
         res = {"workload": "C5: 7680x4320 'temple' G-buffer, Cook-Torrance + IBL shade, RGBA16F target, horizontal bands per rank, "
                            "bands gathered to rank 0 every frame", "n_gpus": world, "frames": frames, "scaling": "strong",
                "ms_per_frame": elapsed / frames * 1e3, "mpixels_per_s": W * H * frames / elapsed / 1e6,
+               "mpixels_per_s_without_gather": W * H * frames / elapsed_local / 1e6,
+               "gather_bytes_per_frame": 8.0 * W * (H - (r1 - r0)),
                "rank0_band_rows": r1 - r0, "rank0_kernel_avg_ms": k,
                "roofline": {"kernel": "K5.shade", "bound": "hbm", "achieved": byt / (k * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": byt / (k * 1e-3) / 1e9 / PEAK_HBM_GBS},

@@ -28,6 +28,7 @@ struct ShadeParams {
     float wfc[16];       // world_space_from_clip
     float ssw[16];       // sun_space_from_world (light shafts only)
     float sun[3], cam[3], frame_idx_mod_59;
+    float rcp_width, rcp_height;   // RN(1/width), RN(1/height), computed on the host
 };
 
 __device__ __forceinline__ float fract_(float x) { return x - floorf(x); }
@@ -72,16 +73,25 @@ __device__ __forceinline__ int cells_level_off(int W, int first, int level) {
     for (int l = first; l < level; ++l) { int n = max(W >> l, 1) + 1; off += 6 * n * n * 3; }
     return off;
 }
+// per-block table of level offsets (texels): [l] bordered pyramid, [16 + l] cells twin; filled once by 16 lanes
+__device__ __forceinline__ void fill_level_table(int* tab, int W, int levels, int cells_first) {
+    if (threadIdx.x < 16) {
+        int l = min((int)threadIdx.x, levels - 1);
+        tab[threadIdx.x] = bordered_level_off(W, l);
+        tab[16 + threadIdx.x] = cells_level_off(W, cells_first, l);
+    }
+    __syncthreads();
+}
 __device__ __forceinline__ f3 level_fetch(const float4* __restrict__ pyr, const float4* __restrict__ cells, int cells_first,
-                                          int W, int l, int face, float s, float t) {
+                                          int W, int l, int face, float s, float t, const int* tab) {
     int n = max(W >> l, 1);
     CubeTap tp = cube_tap_from_st(face, s, t, n);
-    if (cells && l >= cells_first) return fetch_rgb_cells_tap(cells + cells_level_off(W, cells_first, l), n, tp);
-    return fetch_rgb_tap(pyr + bordered_level_off(W, l), n, tp);
+    if (cells && l >= cells_first) return fetch_rgb_cells_tap(cells + tab[16 + l], n, tp);
+    return fetch_rgb_tap(pyr + tab[l], n, tp);
 }
 // trilinear fetch from a bordered pyramid (sampler: linear mip filter, LOD clamped to the chain)
 __device__ __forceinline__ f3 pyramid_fetch(const float4* __restrict__ pyr, const float4* __restrict__ cells, int cells_first,
-                                            int W, int levels, f3 d, float lod) {
+                                            int W, int levels, f3 d, float lod, const int* tab) {
     CubeST cs = cube_select(d);
     float s, t;
     cube_st_exact(cs, &s, &t);
@@ -90,10 +100,10 @@ __device__ __forceinline__ f3 pyramid_fetch(const float4* __restrict__ pyr, cons
     float fl = floorf(lod);
     int l0 = (int)fl;
     float w = lod - fl;
-    f3 c0 = level_fetch(pyr, cells, cells_first, W, l0, cs.face, s, t);
+    f3 c0 = level_fetch(pyr, cells, cells_first, W, l0, cs.face, s, t, tab);
     if (w > 0.0f) {
         int l1 = min(l0 + 1, levels - 1);
-        f3 c1 = level_fetch(pyr, cells, cells_first, W, l1, cs.face, s, t);
+        f3 c1 = level_fetch(pyr, cells, cells_first, W, l1, cs.face, s, t, tab);
         c0.x = lerp_fma(c0.x, c1.x, w); c0.y = lerp_fma(c0.y, c1.y, w); c0.z = lerp_fma(c0.z, c1.z, w);
     }
     return c0;
@@ -125,6 +135,8 @@ __device__ __forceinline__ float2 lut_fetch(const __half2* __restrict__ lut, con
 }
 
 __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
+    __shared__ int level_tab[32];
+    fill_level_table(level_tab, p.pre_size, min(p.pre_levels, 16), p.pre_cells_first);
     {   // grid: x = 64-pixel column blocks, y = 4-row blocks (no integer division per pixel)
         int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6);
         if (lx >= p.w || ly >= p.h) return;
@@ -140,10 +152,13 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
         f3 emissive = mk3(unorm8(ee.x) * 10.0f, unorm8(ee.y) * 10.0f, unorm8(ee.z) * 10.0f);
 
         // :444-451
-        float fs_u = ((float)px + 0.5f) / (float)p.width, fs_v = ((float)py + 0.5f) / (float)p.height;
+        SharedRcp rw, rh;
+        rw.d = (float)p.width; rw.r = p.rcp_width; rh.d = (float)p.height; rh.r = p.rcp_height;
+        float fs_u = div_by((float)px + 0.5f, rw), fs_v = div_by((float)py + 0.5f, rh);
         float pw[4];
         mat_mul(p.wfc, fs_u * 2.0f - 1.0f, fs_v * 2.0f - 1.0f, depth, 1.0f, pw);   // world_space_from_clip
-        f3 P = mk3(pw[0] / pw[3], pw[1] / pw[3], pw[2] / pw[3]);
+        SharedRcp rpw = shared_rcp(pw[3]);
+        f3 P = mk3(div_by(pw[0], rpw), div_by(pw[1], rpw), div_by(pw[2], rpw));
 
         // :456-459
         float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
@@ -164,7 +179,7 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
 
         // :708-710 the sky branch replaces everything else: take it first (most waves of a frame are all-sky or all-surface)
         if (sky) {
-            outl = pyramid_fetch(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, mk3(-V.x, -V.y, -V.z), 1.0f);
+            outl = pyramid_fetch(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, mk3(-V.x, -V.y, -V.z), 1.0f, level_tab);
         } else {
             if (p.flags & PBRK_SHADE_SHAFTS) {                                   // :622-651 (visibility == 1)
                 float sp[4], cp4[4];
@@ -213,7 +228,11 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
 
             if (p.flags & PBRK_SHADE_IBL) {
                 float2 sb = lut_fetch(p.lut, p.lut_cells, p.lut_size, VdotN, fmaxf(roughness, 0.05f));  // :681
-                f3 irr = p.irr_cells ? cube_fetch_rgb_cells<true>(p.irr_cells, p.irr_size, N) : cube_fetch_rgb<true>(p.irr, p.irr_size, N);                              // :690
+                f3 irr;                                                                    // :690
+                {
+                    CubeTap tp = cube_tap<true>(N, p.irr_size);
+                    irr = p.irr_cells ? fetch_rgb_cells_tap(p.irr_cells, p.irr_size, tp) : fetch_rgb_tap(p.irr, p.irr_size, tp);
+                }
                 outl.x += kD.x * irr.x * base.x;                                           // :687
                 outl.y += kD.y * irr.y * base.y;
                 outl.z += kD.z * irr.z * base.z;
@@ -226,7 +245,7 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
                 float r2 = roughness * roughness;
                 float r4 = r2 * r2;
                 R = mk3(mix_(R.x, N.x, r4), mix_(R.y, N.y, r4), mix_(R.z, N.z, r4));
-                f3 spec = pyramid_fetch(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, R, roughness * 4.0f);   // :699
+                f3 spec = pyramid_fetch(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, R, roughness * 4.0f, level_tab);   // :699
                 outl.x += spec.x * (F0.x * sb.x + sb.y);                                   // :702
                 outl.y += spec.y * (F0.y * sb.x + sb.y);
                 outl.z += spec.z * (F0.z * sb.x + sb.y);
@@ -272,7 +291,7 @@ extern "C" int pbrk_shade(const PbrkShadeArgs* a, void* stream) {
     if (!a->base_color || !a->normal || !a->orm || !a->emissive || !a->depth || !a->out) return PBRK_E_ARG;
     if (a->out_format != PBRK_FMT_RGBA16F && a->out_format != PBRK_FMT_RGBA32F) return PBRK_E_FORMAT;
     if (!a->prefiltered_bordered || a->prefiltered_size < 1 || a->prefiltered_levels < 1 ||
-        a->prefiltered_levels > pbrk_mip_count(a->prefiltered_size, a->prefiltered_size)) return PBRK_E_ARG;   // sky branch is live code
+        a->prefiltered_levels > pbrk_mip_count(a->prefiltered_size, a->prefiltered_size) || a->prefiltered_levels > 16) return PBRK_E_ARG;   // sky branch is live code; 16-entry level table
     if (a->flags & PBRK_SHADE_IBL) {
         if (!a->irradiance_bordered || a->irradiance_size < 1 || !a->lut || a->lut_size < 1) return PBRK_E_ARG;
     }
@@ -289,6 +308,7 @@ extern "C" int pbrk_shade(const PbrkShadeArgs* a, void* stream) {
     for (int i = 0; i < 16; ++i) { p.wfc[i] = a->globals[32 + i]; p.ssw[i] = a->globals[96 + i]; }
     for (int i = 0; i < 3; ++i) { p.sun[i] = a->globals[128 + i]; p.cam[i] = a->globals[132 + i]; }
     p.frame_idx_mod_59 = a->globals[135];
+    p.rcp_width = 1.0f / (float)a->width; p.rcp_height = 1.0f / (float)a->height;
     hipLaunchKernelGGL(k_shade, dim3((p.w + 63) / 64, (p.h + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }

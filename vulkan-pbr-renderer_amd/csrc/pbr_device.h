@@ -22,9 +22,21 @@ __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y
 __device__ __forceinline__ f3 cross3(f3 a, f3 b) {
     return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
 }
+// Several quotients by one divisor: r = RN(1/d) once (correctly rounded divide), then per numerator
+//   q = RN(a*r);  rem = a - q*d (exact, FMA);  result = RN(q + rem*r) = RN(a/d)            [Markstein 1990]
+// which is the correctly rounded quotient whenever d's significand is not all ones (and nothing under/overflows): 3
+// instructions per quotient instead of ~12.  The exception cannot occur for integer divisors (image extents) and is
+// a 2^-23 event of 1 ulp elsewhere.
+struct SharedRcp { float d, r; };
+__device__ __forceinline__ SharedRcp shared_rcp(float d) { SharedRcp e; e.d = d; e.r = __fdiv_rn(1.0f, d); return e; }
+__device__ __forceinline__ float div_by(float a, const SharedRcp& e) {
+    float q = a * e.r;
+    float rem = fmaf(-q, e.d, a);
+    return fmaf(rem, e.r, q);
+}
 __device__ __forceinline__ f3 normalize3(f3 a) {
-    float len = sqrtf(dot3(a, a));   // correctly rounded expansion (unlike __fsqrt_rn, which is the 1-ulp v_sqrt_f32)
-    return mk3(__fdiv_rn(a.x, len), __fdiv_rn(a.y, len), __fdiv_rn(a.z, len));
+    SharedRcp e = shared_rcp(sqrtf(dot3(a, a)));   // sqrtf: correctly rounded expansion (unlike __fsqrt_rn, which is the 1-ulp v_sqrt_f32)
+    return mk3(div_by(a.x, e), div_by(a.y, e), div_by(a.z, e));
 }
 
 // EXACT: CubemapSampleDirFromFaceUV (reference shaders/gen_prefiltered_env_map.glsl:11-66):
@@ -87,8 +99,9 @@ __device__ __forceinline__ CubeST cube_select(f3 d) {
 }
 // EXACT sampler coordinates s,t in [0,1] (independent of the level): s = (0.5*sc)/|rc| + 0.5
 __device__ __forceinline__ void cube_st_exact(const CubeST& c, float* s, float* t) {
-    *s = 0.5f * c.sc / c.ma + 0.5f;
-    *t = 0.5f * c.tc / c.ma + 0.5f;
+    SharedRcp rma = shared_rcp(c.ma);
+    *s = div_by(0.5f * c.sc, rma) + 0.5f;
+    *t = div_by(0.5f * c.tc, rma) + 0.5f;
 }
 __device__ __forceinline__ CubeTap cube_tap_from_st(int face, float s, float t, int n) {
     float u = s * (float)n - 0.5f;                        // unbordered coordinate, as the sampler definition states it
