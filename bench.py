@@ -217,7 +217,9 @@ def main():
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
-            if backend != "nccl":
+            if backend == "nccl":
+                torch.cuda.current_stream().synchronize()      # wait() only orders streams: the step ends when its exchange has landed
+            else:
                 for dst, buf in staged:
                     dst.copy_(buf)
 
@@ -484,6 +486,8 @@ def shade_c5_bench(L, pbrhip, env_tex, rank, world, backend, torch, dist, frames
                 ops.append(dist.P2POp(dist.isend, src if backend == "nccl" else src.cpu(), 0))
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+            if backend == "nccl":
+                torch.cuda.current_stream().synchronize()
             for dst, buf in staged:
                 if backend != "nccl":
                     dst.copy_(buf)
