@@ -547,19 +547,27 @@ def post_bench(L, pbrhip, frames=20):
     pbrhip.upload_mip(L.PBR_PostVelocity(pp, 0), 0, vel); pbrhip.upload_mip(L.PBR_PostVelocity(pp, 1), 0, vel_prev)
     pbrhip.upload_mip(L.PBR_PostTaaOutput(pp, 1), 0, history)
     g = L.GPU_MakeGraph()
-    L.PBR_RecordTaaResolve(pp, g, 0); L.PBR_RecordFinalPostProcess(pp, g, 0)
+
+    def record(f):                                                # render.cpp:1131-1187: TAA -> bloom (6 + 6 passes) -> final
+        L.PBR_RecordTaaResolve(pp, g, f); L.PBR_RecordBloom(pp, g, f); L.PBR_RecordFinalPostProcessBloom(pp, g, f)
+    record(0)
     L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
     for f in range(frames):
-        L.PBR_RecordTaaResolve(pp, g, f); L.PBR_RecordFinalPostProcess(pp, g, f)
+        record(f)
     t0 = time.perf_counter()
     L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
     wall = time.perf_counter() - t0
     ms = {}
     for i in range(L.GPUX_GraphTimedOpCount(g)):
         ms.setdefault(L.GPUX_GraphTimedOpName(g, i).decode(), []).append(L.GPUX_GraphTimedOpMs(g, i))
-    res = {"workload": "N3: 1920x1080 TAA resolve + tone map (RGBA16F in, BGRA8 out)", "frames": frames,
-           "mpixels_per_s_wall": W * H * frames / wall / 1e6, "kernels": []}
-    for name, byt in (("K8.taa_resolve", 36.0 * W * H), ("K9.final_post_process", 12.0 * W * H)):
+    res = {"workload": "N3: 1920x1080 TAA resolve + bloom chain (6 down, 6 up) + tone map (RGBA16F in, BGRA8 out)", "frames": frames,
+           "mpixels_per_s_wall": W * H * frames / wall / 1e6, "us_per_frame_kernels": float(sum(sum(v) for v in ms.values()) / frames * 1e3),
+           "note": "bloom entries: mean over the 6 passes of a frame (avg_ms and alg_bytes per pass)", "kernels": []}
+    # bloom bytes: every pass reads its source level once and writes (upsample: reads + writes) its target, 8 B per texel
+    lv = lambda w, h, m: max(1, w >> m) * max(1, h >> m)
+    down_b = sum(8.0 * ((W * H if m == 0 else lv(W // 2, H // 2, m - 1)) + lv(W // 2, H // 2, m)) for m in range(6)) / 6
+    up_b = sum(8.0 * (lv(W // 2, H // 2, 5) if m == 5 else lv(W, H, m + 1)) + 16.0 * lv(W, H, m) for m in range(6)) / 6
+    for name, byt in (("K8.taa_resolve", 36.0 * W * H), ("K10.bloom_downsample", down_b), ("K11.bloom_upsample", up_b), ("K9.final_post_process", 12.0 * W * H)):
         k_ms = float(np.mean(ms[name]))
         res["kernels"].append({"kernel": name, "avg_ms": k_ms, "bound": "hbm", "alg_bytes": byt,
                                "achieved": byt / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -135,6 +135,14 @@ GPU_Texture* PBR_PostBackbuffer(PBR_PostProcess* pp);
 void PBR_RecordTaaResolve(PBR_PostProcess* pp, GPU_Graph* graph, uint32_t frame_idx);
 void PBR_RecordTaaResolveRows(PBR_PostProcess* pp, GPU_Graph* graph, uint32_t frame_idx, uint32_t row0, uint32_t row1);   /* rows [row0,row1) only */
 void PBR_RecordFinalPostProcess(PBR_PostProcess* pp, GPU_Graph* graph, uint32_t frame_idx);
+/* bloom chain between the two (render.cpp:741-777, 340-454, 1139-1176): BLOOM_PASS_COUNT (6, or fewer on tiny frames) 13-tap
+ * downsamples into the mips of a half-size target, clear + blit of the TAA result into the full-size target, as many additive
+ * tent upsamples; then the final pass reading that target, as the reference binds it (render.cpp:478). */
+void PBR_RecordBloom(PBR_PostProcess* pp, GPU_Graph* graph, uint32_t frame_idx);
+void PBR_RecordFinalPostProcessBloom(PBR_PostProcess* pp, GPU_Graph* graph, uint32_t frame_idx);
+GPU_Texture* PBR_PostBloomDownscale(PBR_PostProcess* pp);
+GPU_Texture* PBR_PostBloomUpscale(PBR_PostProcess* pp);
+uint32_t PBR_PostBloomPassCount(const PBR_PostProcess* pp);
 
 #ifdef __cplusplus
 }

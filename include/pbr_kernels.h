@@ -169,6 +169,21 @@ typedef struct PbrkFinalArgs {
 } PbrkFinalArgs;
 int pbrk_final_post_process(const PbrkFinalArgs* args, void* stream);
 
+/* K10 / K11: one pass of the bloom chain (render.cpp:1139-1176): bloom_downsample.glsl:38-98 (13 bilinear taps; firefly
+ * clamp when dst_mip_level == 1) or bloom_upsample.glsl:23-58 (3x3 tent at radius 1.5 source texels; x0.06 when
+ * dst_mip_level == 0) from `src` into an RGBA16F target of dst_width x dst_height.  blend_additive: target = fp16(colour +
+ * target) with alpha = 1 (VK_BLEND_FACTOR_ONE / ONE, alpha ONE / ZERO; gpu_vulkan.c:1828-1842). */
+typedef struct PbrkBloomArgs {
+    PbrkTex2D src;                      /* RGBA16F (a mip of a texture: data points at the level, width/height are the level's) */
+    void* dst;                          /* half4 [dst_height][dst_width] */
+    int dst_width, dst_height;
+    int dst_mip_level;                  /* the shader's push constant */
+    int upsample;                       /* 0: bloom_downsample.glsl, 1: bloom_upsample.glsl */
+    int blend_additive;
+    int y0, y1;
+} PbrkBloomArgs;
+int pbrk_bloom_pass(const PbrkBloomArgs* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -236,8 +236,11 @@ int main(int argc, char** argv) {
     std::vector<float> out((size_t)W * H * 4);
     for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
         gl_FragCoord = vec4(x + 0.5f, y + 0.5f, 0.5f, 1.0f);
-#if defined(KIND_FINAL)
+#if defined(KIND_FINAL) || defined(KIND_BLOOM)
         S::fs_uv = vec2((x + 0.5f) / (float)W, (y + 0.5f) / (float)H);
+#endif
+#if defined(KIND_BLOOM)
+        S::PC.dst_mip_level = atoi(getenv("DST_MIP"));
 #endif
         S::shader_main();
         float* o = &out[((size_t)y * W + x) * 4];
@@ -416,6 +419,49 @@ def gen_post(meta):
                             "note": "final_* = tone map of the resolved frame stored as RGBA16F; final_up renders at 2x the source size"}
 
 
+def gen_bloom(meta):
+    """render.cpp:1139-1176 with every fragment colour produced by the reference's shader text; render-target semantics
+    (RGBA16F store = RTE, additive blend = fp16(src + dst), alpha = src) are this repo's (see oracle bloom_chain)."""
+    import pbr_oracle as O
+    from pbrhip import synth
+    W, H, passes = 256, 144, 6
+    lighting, _, _, _, _ = synth.synth_post_inputs(0x5EED00C8, W, H)
+    taa = lighting                                           # any RGBA16F frame serves as the TAA result
+    exes = {False: build("bloom_down", "bloom_downsample.glsl", DRIVER_POST, ["KIND_BLOOM"]),
+            True: build("bloom_up", "bloom_upsample.glsl", DRIVER_POST, ["KIND_BLOOM"])}
+
+    def run_pass(src, dw, dh, dst_mip, up):
+        sp = os.path.join(SCRATCH, "bloom_src.bin"); op = os.path.join(SCRATCH, "bloom_out.bin")
+        np.ascontiguousarray(src).tofile(sp)
+        env = dict(os.environ, DST_MIP=str(dst_mip))
+        subprocess.check_call([exes[up], "bloom", str(dw), str(dh), op, "33", "0", str(src.shape[1]), str(src.shape[0]), sp], env=env)
+        return np.fromfile(op, dtype=np.float32).reshape(dh, dw, 4)
+
+    dims = lambda w, h, m: (max(1, w >> m), max(1, h >> m))
+    down, src = [], taa
+    for step in range(passes):
+        dw, dh = dims(W // 2, H // 2, step)
+        down.append(run_pass(src, dw, dh, step + 1, False).astype(np.float16)); src = down[-1]
+    up = [np.zeros(dims(W, H, m)[::-1] + (4,), np.float16) for m in range(passes)]
+    up[0] = taa.copy()
+    for step in range(passes):
+        dst_level = passes - 1 - step
+        src = down[passes - 1] if step == 0 else up[passes - step]
+        dw, dh = dims(W, H, dst_level)
+        frag = run_pass(src, dw, dh, dst_level, True)
+        up[dst_level] = np.concatenate([frag[..., :3] + up[dst_level][..., :3].astype(np.float32), frag[..., 3:]], axis=-1).astype(np.float16)
+    mine_down, mine_up = O.bloom_chain(taa, passes)
+    bad = sum(int((a.view(np.uint16) != b.view(np.uint16)).sum()) for a, b in zip(down + up, mine_down + mine_up))
+    print("bloom: oracle-B mismatching halfs over all 12 targets:", bad)
+    save = {"taa": taa.view(np.uint16)}
+    for m in range(passes):
+        save[f"down{m}"] = down[m].view(np.uint16); save[f"up{m}"] = up[m].view(np.uint16)
+    np.savez_compressed(os.path.join(GOLDEN, "oracle_a_bloom.npz"), **save)
+    meta["bloom"] = {"file": "oracle_a_bloom.npz", "width": W, "height": H, "passes": passes, "seed": 0x5EED00C8,
+                     "shaders": ["bloom_downsample.glsl", "bloom_upsample.glsl"],
+                     "note": "down{m} = bloom_downscale_rt mip m, up{m} = bloom_upscale_rt mip m after the whole chain (RGBA16F bits)"}
+
+
 def main():
     import pbr_oracle as O
     from pbrhip import synth
@@ -425,7 +471,7 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--only":       # regenerate one group, keep the rest of the metadata
         with open(os.path.join(GOLDEN, "oracle_a_meta.json")) as f:
             meta = json.load(f)
-        {"sweep": gen_sweep, "post": gen_post}[sys.argv[2]](meta)
+        {"sweep": gen_sweep, "post": gen_post, "bloom": gen_bloom}[sys.argv[2]](meta)
         with open(os.path.join(GOLDEN, "oracle_a_meta.json"), "w") as f:
             json.dump(meta, f, indent=1)
         return
@@ -538,6 +584,7 @@ def main():
 
     gen_sweep(meta)
     gen_post(meta)
+    gen_bloom(meta)
 
     with open(os.path.join(GOLDEN, "oracle_a_meta.json"), "w") as f:
         json.dump(meta, f, indent=1)

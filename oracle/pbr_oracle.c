@@ -1015,3 +1015,50 @@ uint8_t orc_unorm8(float v) {
     v = fminf(fmaxf(v, 0.0f), 1.0f);
     return (uint8_t)lrintf(v * 255.0f);                            /* round to nearest even (default rounding mode) */
 }
+
+/* ---- bloom chain (post-process, between TAA and the final pass) ---- */
+void orc_bloom_downsample(const OrcTex2D* src, int dw, int dh, int dst_mip_level, float* out_rgba) {
+    #pragma omp parallel for schedule(static) num_threads(ORC_NT())
+    for (int py = 0; py < dh; ++py)
+        for (int px = 0; px < dw; ++px) {
+            float u = ((float)px + 0.5f) / (float)dw, v = ((float)py + 0.5f) / (float)dh;
+            float x = 1.0f / (float)src->width, y = 1.0f / (float)src->height;          /* :40-42 */
+            static const float ox[13] = {-2, 0, 2, -2, 0, 2, -2, 0, 2, -1, 1, -1, 1};     /* a b c d e f g h i j k l m (:50-64) */
+            static const float oy[13] = {-2, -2, -2, 0, 0, 0, 2, 2, 2, -1, -1, 1, 1};
+            float t[13][4];
+            for (int k = 0; k < 13; ++k) orc_tex2d_sample(src, u + ox[k] * x, v + oy[k] * y, t[k]);
+            float* o = out_rgba + ((size_t)py * dw + px) * 4;
+            for (int c = 0; c < 3; ++c) {
+                float sum = t[4][c] * 0.125f;                                                   /* :90 */
+                sum = sum + (((t[0][c] + t[2][c]) + t[6][c]) + t[8][c]) * 0.03125f;             /* :91 (a+c+g+i) */
+                sum = sum + (((t[1][c] + t[3][c]) + t[5][c]) + t[7][c]) * 0.0625f;              /* :92 (b+d+f+h) */
+                sum = sum + (((t[9][c] + t[10][c]) + t[11][c]) + t[12][c]) * 0.125f;            /* :93 (j+k+l+m) */
+                if (dst_mip_level == 1) sum = fminf(sum, 1.0f);                                 /* :94-97 */
+                o[c] = sum;
+            }
+            o[3] = 1.0f;
+        }
+}
+
+void orc_bloom_upsample(const OrcTex2D* src, int dw, int dh, int dst_mip_level, float* out_rgba) {
+    #pragma omp parallel for schedule(static) num_threads(ORC_NT())
+    for (int py = 0; py < dh; ++py)
+        for (int px = 0; px < dw; ++px) {
+            float u = ((float)px + 0.5f) / (float)dw, v = ((float)py + 0.5f) / (float)dh;
+            const float radius = 1.5f;                                                          /* :26-28 */
+            float x = radius / (float)src->width, y = radius / (float)src->height;
+            float factor = 1.0f;
+            if (dst_mip_level == 0) factor = 0.06f;                                             /* :37 */
+            static const float ox[9] = {-1, 0, 1, -1, 0, 1, -1, 0, 1}, oy[9] = {-1, -1, -1, 0, 0, 0, 1, 1, 1};   /* a..i (:43-51) */
+            float t[9][4];
+            for (int k = 0; k < 9; ++k) orc_tex2d_sample(src, u + ox[k] * x, v + oy[k] * y, t[k]);
+            float* o = out_rgba + ((size_t)py * dw + px) * 4;
+            for (int c = 0; c < 3; ++c) {
+                float sum = t[4][c] * 4.0f;                                                     /* :55 */
+                sum = sum + (((t[1][c] + t[3][c]) + t[5][c]) + t[7][c]) * 2.0f;                 /* :56 */
+                sum = sum + (((t[0][c] + t[2][c]) + t[6][c]) + t[8][c]);                        /* :57 */
+                o[c] = sum * factor / 16.0f;                                                    /* :58 */
+            }
+            o[3] = 1.0f;
+        }
+}

@@ -98,6 +98,11 @@ typedef struct OrcTaaInputs {
 void   orc_taa_resolve(const OrcTaaInputs* in, int width, int height, int y0, int y1, float* out_rgba);
 /* fs_uv = ((x+.5)/width, (y+.5)/height) (full-screen triangle, final_post_process.glsl:16-19); out float RGBA */
 void   orc_final_post_process(const OrcTex2D* bloom_result, int width, int height, int y0, int y1, float* out_rgba);
+/* bloom_downsample.glsl:38-98 (13 bilinear taps, firefly clamp when dst_mip_level == 1) and bloom_upsample.glsl:23-58
+ * (3x3 tent, radius 1.5 source texels, factor 0.06 when dst_mip_level == 0): the fragment colour for every pixel of a
+ * dw x dh target, fs_uv = ((x+.5)/dw, (y+.5)/dh).  Blending and the RGBA16F store are the caller's (render.cpp:1139-1176). */
+void   orc_bloom_downsample(const OrcTex2D* src, int dw, int dh, int dst_mip_level, float* out_rgba);
+void   orc_bloom_upsample(const OrcTex2D* src, int dw, int dh, int dst_mip_level, float* out_rgba);
 /* render-target conversion of a float colour to 8-bit unorm (round to nearest even of clamp(v,0,1)*255) */
 uint8_t orc_unorm8(float v);
 

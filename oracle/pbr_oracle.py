@@ -106,6 +106,8 @@ def lib():
     L.orc_tex2d_sample.argtypes = [C.POINTER(OrcTex2D), C.c_float, C.c_float, f32p]
     L.orc_taa_resolve.argtypes = [C.POINTER(OrcTaaInputs), C.c_int, C.c_int, C.c_int, C.c_int, f32p]
     L.orc_final_post_process.argtypes = [C.POINTER(OrcTex2D), C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+    L.orc_bloom_downsample.argtypes = [C.POINTER(OrcTex2D), C.c_int, C.c_int, C.c_int, f32p]
+    L.orc_bloom_upsample.argtypes = [C.POINTER(OrcTex2D), C.c_int, C.c_int, C.c_int, f32p]
     L.orc_unorm8.argtypes = [C.c_float]
     L.orc_unorm8.restype = C.c_uint8
     L.orc_shade.argtypes = [C.POINTER(OrcGlobals), C.POINTER(OrcShadeInputs), C.c_int,
@@ -350,3 +352,37 @@ def final_post_process(src_rgba16f, width=None, height=None):
 def unorm8(arr):
     f = np.clip(np.asarray(arr, np.float32), 0.0, 1.0) * np.float32(255.0)
     return np.rint(f).astype(np.uint8)                    # rint = round half to even, like lrintf
+
+
+def bloom_pass(src_rgba16f, dw, dh, dst_mip_level, up):
+    t, keep = _tex2d(src_rgba16f, TEX_RGBA16F)
+    out = np.zeros((dh, dw, 4), np.float32)
+    (lib().orc_bloom_upsample if up else lib().orc_bloom_downsample)(C.byref(t), dw, dh, int(dst_mip_level), out.reshape(-1))
+    return out
+
+
+def bloom_chain(taa_rgba16f, passes=6):
+    """render.cpp:1139-1176 on the CPU: `passes` downsamples into the mips of bloom_downscale_rt (half size), clear +
+    1:1 blit of the TAA result into bloom_upscale_rt mip 0, `passes` additive upsamples.  Render targets are RGBA16F:
+    every pass stores fp16 (RTE); additive blending = fp16(src + dst) with alpha = src alpha (ONE, ZERO).
+    Returns (downscale_mips, upscale_mips) as lists of float16 arrays."""
+    taa = np.asarray(taa_rgba16f)
+    taa = taa.view(np.float16) if taa.dtype == np.uint16 else taa.astype(np.float16)
+    H, W = taa.shape[:2]
+    dims = lambda w, h, m: (max(1, w >> m), max(1, h >> m))
+    down = []
+    src = taa
+    for step in range(passes):                              # :1141-1152, dst_mip_level = step + 1
+        dw, dh = dims(W // 2, H // 2, step)
+        down.append(bloom_pass(src, dw, dh, step + 1, up=False).astype(np.float16))
+        src = down[-1]
+    up = [np.zeros(dims(W, H, m)[::-1] + (4,), np.float16) for m in range(passes)]      # :1156 clear
+    up[0] = taa.copy()                                      # :1158-1163 blit
+    for step in range(passes):                              # :1165-1176, dst level = passes - 1 - step
+        dst_level = passes - 1 - step
+        src = down[passes - 1] if step == 0 else up[passes - step]
+        dw, dh = dims(W, H, dst_level)
+        frag = bloom_pass(src, dw, dh, dst_level, up=True)
+        blended = frag[..., :3] + up[dst_level][..., :3].astype(np.float32)
+        up[dst_level] = np.concatenate([blended, frag[..., 3:]], axis=-1).astype(np.float16)
+    return down, up

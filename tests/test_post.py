@@ -197,3 +197,93 @@ def test_gpu_post_boundary_errors(gpu):
         L.PBR_DestroyPostProcess(pp); L.PBR_DestroyGBuffer(C.byref(gb))
     finally:
         L.GPUX_SetErrorHandler(None, None)
+
+
+# ------------------------------------------------------------------------------------------- bloom chain
+
+@pytest.fixture(scope="module")
+def bloom_fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, "oracle_a_bloom.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def test_oracle_bloom_chain_matches_reference_shaders(bloom_fixture):
+    f = bloom_fixture
+    down, up = O.bloom_chain(f["taa"], 6)
+    for m in range(6):
+        assert np.array_equal(down[m].view(np.uint16), f[f"down{m}"]), f"down{m}"
+        assert np.array_equal(up[m].view(np.uint16), f[f"up{m}"]), f"up{m}"
+    taa = f["taa"].view(np.float16).astype(np.float32)
+    glow = f["up0"].view(np.float16).astype(np.float32)[..., :3] - taa[..., :3]
+    assert glow.min() > -1e-2 and glow.mean() > 0                   # level 0 = the frame + 6 % of the blurred pyramid
+    assert f["down0"].view(np.float16).astype(np.float32)[..., :3].max() <= 1.0     # firefly clamp of the first downsample
+
+
+def _check_bloom(L, pbrhip, pp, want_down, want_up):
+    n = L.PBR_PostBloomPassCount(pp)
+    assert n == len(want_down)
+    for m in range(n):
+        got = pbrhip.read_mip(L.PBR_PostBloomDownscale(pp), m)
+        assert np.array_equal(got.view(np.uint16), np.asarray(want_down[m]).view(np.uint16)), f"bloom_downscale_rt mip {m}"
+        got = pbrhip.read_mip(L.PBR_PostBloomUpscale(pp), m)
+        assert np.array_equal(got.view(np.uint16), np.asarray(want_up[m]).view(np.uint16)), f"bloom_upscale_rt mip {m}"
+
+
+@pytest.mark.gpu
+def test_gpu_bloom_chain_matches_reference_shaders(gpu, bloom_fixture):
+    """render.cpp:1139-1187 through the boundary: 6 downsamples, clear, blit, 6 additive upsamples, final pass reading the
+    bloom target; all twelve RGBA16F targets bit-exact against the shader text, the 8-bit frame within one code."""
+    import pbrhip
+    L, f = gpu, bloom_fixture
+    h, w = f["taa"].shape[:2]
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), w, h, pbrhip.Format_RGBA16F)
+    pp = L.PBR_MakePostProcess(C.byref(gb), w, h, pbrhip.Format_RGBA8UN)
+    frame_idx = 1
+    _upload(L.PBR_PostTaaOutput(pp, frame_idx % 2), f["taa"])
+    L.GPUX_EnableOpTiming(1)
+    g = L.GPU_MakeGraph()
+    L.PBR_RecordBloom(pp, g, frame_idx)
+    L.PBR_RecordFinalPostProcessBloom(pp, g, frame_idx)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    names = [L.GPUX_GraphTimedOpName(g, i).decode() for i in range(L.GPUX_GraphTimedOpCount(g))]
+    assert names == ["K10.bloom_downsample"] * 6 + ["blit_1to1"] + ["K11.bloom_upsample"] * 6 + ["K9.final_post_process"], names
+    L.GPU_DestroyGraph(g)
+    _check_bloom(L, pbrhip, pp, [f[f"down{m}"] for m in range(6)], [f[f"up{m}"] for m in range(6)])
+    bb = pbrhip.read_mip(L.PBR_PostBackbuffer(pp), 0)
+    want8 = O.unorm8(O.final_post_process(f["up0"]))
+    assert np.abs(bb.astype(np.int32) - want8.astype(np.int32)).max() <= 1
+    L.PBR_DestroyPostProcess(pp); L.PBR_DestroyGBuffer(C.byref(gb))
+
+
+@pytest.mark.gpu
+def test_gpu_bloom_full_frame_and_errors(gpu):
+    """1920x1080 (odd mip sizes: 135 -> 67 -> 33 rows): bit-exact against the oracle chain; a second run gives the same
+    bits (the clear restarts the additive targets); blending other than the bloom's is rejected."""
+    import pbrhip
+    from pbrhip.synth import synth_post_inputs
+    L = gpu
+    W, H = 1920, 1080
+    taa, _, _, _, _ = synth_post_inputs(0x5EED00D7, W, H)
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), W, H, pbrhip.Format_RGBA16F)
+    pp = L.PBR_MakePostProcess(C.byref(gb), W, H, pbrhip.Format_BGRA8UN)
+    _upload(L.PBR_PostTaaOutput(pp, 0), taa)
+    want_down, want_up = O.bloom_chain(taa, 6)
+    for _ in range(2):
+        g = L.GPU_MakeGraph()
+        L.PBR_RecordBloom(pp, g, 0)
+        L.GPU_GraphSubmit(g); L.GPU_GraphWait(g); L.GPU_DestroyGraph(g)
+        _check_bloom(L, pbrhip, pp, want_down, want_up)
+    msgs = []
+    CB = C.CFUNCTYPE(None, C.c_char_p, C.c_void_p)
+    cb = CB(lambda m, u: msgs.append(m.decode()))
+    L.GPUX_SetErrorHandler(C.cast(cb, C.c_void_p), None)
+    try:
+        g = L.GPU_MakeGraph()
+        blit = (C.c_uint8 * 64)()                                                # GPU_OpBlitInfo with a size mismatch: {filter, src, dst, ...}
+        n = len(msgs); L.GPU_OpBlit(g, None); assert len(msgs) == n + 1
+        L.GPU_DestroyGraph(g)
+    finally:
+        L.GPUX_SetErrorHandler(None, None)
+    L.PBR_DestroyPostProcess(pp); L.PBR_DestroyGBuffer(C.byref(gb))

@@ -48,7 +48,7 @@ static void gpu_fail(const char* fmt, ...) {
 // object model
 // ------------------------------------------------------------------------------------------
 enum BindKind { Bind_Texture, Bind_Sampler, Bind_Buffer, Bind_StorageImage };
-enum KernelId { Kernel_None = 0, Kernel_BrdfLut, Kernel_Irradiance, Kernel_Prefilter, Kernel_Lighting, Kernel_LightgridSweep, Kernel_TaaResolve, Kernel_FinalPost };
+enum KernelId { Kernel_None = 0, Kernel_BrdfLut, Kernel_Irradiance, Kernel_Prefilter, Kernel_Lighting, Kernel_LightgridSweep, Kernel_TaaResolve, Kernel_FinalPost, Kernel_BloomDown, Kernel_BloomUp };
 
 struct GPU_Sampler { GPU_SamplerDesc desc; bool shared; };
 
@@ -82,7 +82,7 @@ struct GPU_DescriptorArena { std::vector<GPU_DescriptorSet*> sets; };
 
 struct GPU_ComputePipeline { GPU_PipelineLayout* layout; KernelId kernel; };
 struct GPU_RenderPass { GPU_RenderPassDesc desc; std::vector<GPU_TextureView> targets; };
-struct GPU_GraphicsPipeline { GPU_PipelineLayout* layout; GPU_RenderPass* pass; KernelId kernel; int shade_flags; };
+struct GPU_GraphicsPipeline { GPU_PipelineLayout* layout; GPU_RenderPass* pass; KernelId kernel; int shade_flags; bool blend_additive = false; };
 
 enum OpKind { Op_Dispatch, Op_Shade, Op_MipGen, Op_CopyB2T, Op_CopyT2B, Op_CopyB2B, Op_Blit, Op_Clear };
 struct Op {
@@ -148,6 +148,8 @@ static const char kTokenLit[] = "HIPK5:lighting_pass";
 static const char kTokenSweep[] = "HIPK7:lightgrid_sweep";
 static const char kTokenTaa[] = "HIPK8:taa_resolve";
 static const char kTokenFinal[] = "HIPK9:final_post_process";
+static const char kTokenBloomDown[] = "HIPK10:bloom_downsample";
+static const char kTokenBloomUp[] = "HIPK11:bloom_upsample";
 
 // ------------------------------------------------------------------------------------------
 // formats  [gpu.h:99-144]
@@ -500,6 +502,8 @@ static KernelId identify_shader(const GPU_ShaderDesc* d) {
         if (t == kTokenSweep) return Kernel_LightgridSweep;
         if (t == kTokenTaa) return Kernel_TaaResolve;
         if (t == kTokenFinal) return Kernel_FinalPost;
+        if (t == kTokenBloomDown) return Kernel_BloomDown;
+        if (t == kTokenBloomUp) return Kernel_BloomUp;
         return Kernel_None;
     }
     std::string b = basename_of(d->glsl_debug_filepath);
@@ -510,6 +514,8 @@ static KernelId identify_shader(const GPU_ShaderDesc* d) {
     if (b == "lighting_pass.glsl" && glsl_contains(d->glsl, "BRDF_INTEGRATION_MAP") && glsl_contains(d->glsl, "GBUFFER_DEPTH")) return Kernel_Lighting;
     if (b == "taa_resolve.glsl" && glsl_contains(d->glsl, "SampleHistoryTextureCatmullRom") && glsl_contains(d->glsl, "GBUFFER_VELOCITY_PREV")) return Kernel_TaaResolve;
     if (b == "final_post_process.glsl" && glsl_contains(d->glsl, "aces_approx") && glsl_contains(d->glsl, "BLOOM_RESULT")) return Kernel_FinalPost;
+    if (b == "bloom_downsample.glsl" && glsl_contains(d->glsl, "BLOOM_INPUT") && glsl_contains(d->glsl, "dst_mip_level")) return Kernel_BloomDown;
+    if (b == "bloom_upsample.glsl" && glsl_contains(d->glsl, "BLOOM_INPUT") && glsl_contains(d->glsl, "radius")) return Kernel_BloomUp;
     if (b == "lightgrid_sweep.glsl" && glsl_contains(d->glsl, "LIGHTMAP_IMG") && glsl_contains(d->glsl, "X_direction")) return Kernel_LightgridSweep;
     return Kernel_None;
 }
@@ -522,6 +528,8 @@ static GPU_String token_for(KernelId k) {
     case Kernel_LightgridSweep: return GPU_String{kTokenSweep, sizeof kTokenSweep - 1};
     case Kernel_TaaResolve: return GPU_String{kTokenTaa, sizeof kTokenTaa - 1};
     case Kernel_FinalPost: return GPU_String{kTokenFinal, sizeof kTokenFinal - 1};
+    case Kernel_BloomDown: return GPU_String{kTokenBloomDown, sizeof kTokenBloomDown - 1};
+    case Kernel_BloomUp: return GPU_String{kTokenBloomUp, sizeof kTokenBloomUp - 1};
     default: return GPU_String{nullptr, 0};
     }
 }
@@ -536,7 +544,7 @@ GPU_API GPU_String GPU_SPIRVFromGLSL(DS_Arena* arena, GPU_ShaderStage stage, GPU
     GPU_ShaderDesc probe = *desc;
     probe.spirv = empty;
     KernelId k = identify_shader(&probe);
-    bool stage_ok = (k == Kernel_Lighting || k == Kernel_TaaResolve || k == Kernel_FinalPost) ? (stage == GPU_ShaderStage_Vertex || stage == GPU_ShaderStage_Fragment)
+    bool stage_ok = (k == Kernel_Lighting || k == Kernel_TaaResolve || k == Kernel_FinalPost || k == Kernel_BloomDown || k == Kernel_BloomUp) ? (stage == GPU_ShaderStage_Vertex || stage == GPU_ShaderStage_Fragment)
                                            : (stage == GPU_ShaderStage_Compute);
     if (k != Kernel_None && stage_ok) {
         if (out_errors) { out_errors->data = nullptr; out_errors->length = 0; }
@@ -544,7 +552,7 @@ GPU_API GPU_String GPU_SPIRVFromGLSL(DS_Arena* arena, GPU_ShaderStage stage, GPU
     }
     snprintf(g_last_error_text, sizeof g_last_error_text,
              "the HIP backend has no built-in kernel for shader \"%s\" (stage %d); supported: gen_brdf_integration_map.glsl, "
-             "gen_irradiance_map.glsl, gen_prefiltered_env_map.glsl, lightgrid_sweep.glsl (compute), lighting_pass.glsl, taa_resolve.glsl, final_post_process.glsl (full-screen)",
+             "gen_irradiance_map.glsl, gen_prefiltered_env_map.glsl, lightgrid_sweep.glsl (compute), lighting_pass.glsl, taa_resolve.glsl, bloom_downsample.glsl, bloom_upsample.glsl, final_post_process.glsl (full-screen)",
              basename_of(desc->glsl_debug_filepath).c_str(), (int)stage);
     if (!out_errors) { gpu_fail("GPU_SPIRVFromGLSL: %s", g_last_error_text); return empty; }
     g_last_error.shader_stage = stage; g_last_error.line = 0;
@@ -607,13 +615,19 @@ GPU_API void GPU_DestroyRenderPass(GPU_RenderPass* rp) { delete rp; }
 GPU_API GPU_GraphicsPipeline* GPU_MakeGraphicsPipeline(const GPU_GraphicsPipelineDesc* desc) {
     GPU_REQUIRE(desc && desc->layout && desc->render_pass, nullptr, "GPU_MakeGraphicsPipeline: NULL argument");
     KernelId k = identify_shader(&desc->fs);
-    GPU_REQUIRE(k == Kernel_Lighting || k == Kernel_TaaResolve || k == Kernel_FinalPost, nullptr,
+    GPU_REQUIRE(k == Kernel_Lighting || k == Kernel_TaaResolve || k == Kernel_FinalPost || k == Kernel_BloomDown || k == Kernel_BloomUp, nullptr,
                 "GPU_MakeGraphicsPipeline: unsupported (raster): only the full-screen lighting_pass / taa_resolve / final_post_process pipelines have HIP kernels (got \"%s\")",
                 basename_of(desc->fs.glsl_debug_filepath).c_str());
     GPU_REQUIRE(desc->vertex_input_formats_count == 0, nullptr, "GPU_MakeGraphicsPipeline: unsupported (raster): vertex inputs");
     GPU_REQUIRE(desc->render_pass->desc.color_targets_count == 1, nullptr, "GPU_MakeGraphicsPipeline: full-screen passes have exactly one colour target");
     GPU_GraphicsPipeline* p = new GPU_GraphicsPipeline();
     p->layout = desc->layout; p->pass = desc->render_pass; p->kernel = k; p->shade_flags = GPUX_Shade_IBL;
+    if (desc->enable_blending) {                                              // gpu_vulkan.c:1828-1842
+        if (!(desc->blending_mode_additive && (k == Kernel_BloomDown || k == Kernel_BloomUp))) {
+            gpu_fail("GPU_MakeGraphicsPipeline: blending is implemented for the additive bloom passes only"); delete p; return nullptr;
+        }
+        p->blend_additive = true;
+    }
     return p;
 }
 GPU_API void GPU_DestroyGraphicsPipeline(GPU_GraphicsPipeline* p) { delete p; }
@@ -859,10 +873,30 @@ static bool check_post_plane(Slot* s, GPU_Format f, uint32_t w, uint32_t h, cons
 static void record_post(GPU_Graph* g, const DrawParams& dp, uint32_t row0, uint32_t row1, bool explicit_rows, const char* fn) {
     GPU_RenderPass* rp = g->in_pass;
     uint32_t W = rp->desc.width, H = rp->desc.height;
-    GPU_REQUIRE_V(rp->targets.size() == 1 && rp->targets[0].texture && rp->targets[0].mip_level == 0, "%s: the pass needs one colour target (mip 0)", fn);
+    GPU_REQUIRE_V(rp->targets.size() == 1 && rp->targets[0].texture && rp->targets[0].mip_level < rp->targets[0].texture->mip_level_count, "%s: the pass needs one colour target", fn);
     TextureImpl* target = (TextureImpl*)rp->targets[0].texture;
-    GPU_REQUIRE_V(target->base.width == W && target->base.height == H && target->base.layer_count == 1, "%s: colour target must be a %ux%u 2D texture", fn, W, H);
+    const uint32_t tmip = rp->targets[0].mip_level;
+    const bool bloom = dp.pipeline->kernel == Kernel_BloomDown || dp.pipeline->kernel == Kernel_BloomUp;
+    GPU_REQUIRE_V(bloom || tmip == 0, "%s: only the bloom passes render into mip levels", fn);
+    GPU_REQUIRE_V(mip_dim(target->base.width, tmip) == W && mip_dim(target->base.height, tmip) == H && target->base.layer_count == 1 && target->base.depth == 1,
+                  "%s: colour target (mip %u) must be %ux%u", fn, tmip, W, H);
     GPU_DescriptorSet* s = dp.set;
+    if (bloom) {                                                              // bloom_*.glsl: TEX0 = BLOOM_INPUT (a texture or one of its mips), int dst_mip_level pushed
+        GPU_REQUIRE_V(target->base.format == GPU_Format_RGBA16F, "%s: bloom targets are RGBA16F (render.cpp:742-746)", fn);
+        Slot* in = named_slot(s, "TEX0");
+        GPU_REQUIRE_V(in && in->tex && in->tex->base.format == GPU_Format_RGBA16F && in->tex->base.layer_count == 1 && in->tex->base.depth == 1, "%s: \"TEX0\" must be an RGBA16F 2D texture", fn);
+        uint32_t smip = in->whole ? 0 : in->mip;
+        GPU_REQUIRE_V(!(in->tex == target && smip == tmip), "%s: bloom pass reads the level it writes", fn);
+        GPU_REQUIRE_V(g->push_size >= 4, "%s: the bloom shaders need their `int dst_mip_level` push constant", fn);
+        Op op;
+        op.kind = Op_Shade; op.gpipe = dp.pipeline; op.set = s; op.pass = rp;
+        memcpy(op.push, g->push, g->push_size); op.push_size = g->push_size;
+        op.mip = smip; op.mip2 = tmip;
+        op.row0 = explicit_rows ? row0 : 0; op.row1 = explicit_rows ? row1 : H;
+        GPU_REQUIRE_V(op.row0 < op.row1 && op.row1 <= H, "%s: rows [%u,%u) outside the %u-row pass", fn, op.row0, op.row1, H);
+        g->ops.push_back(op);
+        return;
+    }
     if (dp.pipeline->kernel == Kernel_TaaResolve) {
         GPU_REQUIRE_V(target->base.format == GPU_Format_RGBA16F || target->base.format == GPU_Format_RGBA32F, "%s: TAA target must be RGBA16F/RGBA32F", fn);
         if (!check_post_plane(named_slot(s, "LIGHTING_RESULT"), GPU_Format_RGBA16F, W, H, "LIGHTING_RESULT", fn)) return;
@@ -893,7 +927,7 @@ static void record_shade(GPU_Graph* g, uint32_t row0, uint32_t row1, bool explic
     GPU_REQUIRE_V(dp.set->layout == dp.pipeline->layout, "%s: descriptor set and pipeline use different layouts", fn);
     GPU_RenderPass* rp = g->in_pass;
     uint32_t W = rp->desc.width, H = rp->desc.height;
-    if (dp.pipeline->kernel == Kernel_TaaResolve || dp.pipeline->kernel == Kernel_FinalPost) {
+    if (dp.pipeline->kernel == Kernel_TaaResolve || dp.pipeline->kernel == Kernel_FinalPost || dp.pipeline->kernel == Kernel_BloomDown || dp.pipeline->kernel == Kernel_BloomUp) {
         record_post(g, dp, row0, row1, explicit_rows, fn);
         return;
     }
@@ -991,6 +1025,22 @@ GPU_API void GPU_OpBlit(GPU_Graph* g, const GPU_OpBlitInfo* info) {
     GPU_REQUIRE_V(info && info->src_texture && info->dst_texture, "GPU_OpBlit: NULL argument");
     const GPU_Texture* s = info->src_texture; const GPU_Texture* d = info->dst_texture;
     if (s == d) GPU_REQUIRE_V(info->dst_mip_level != info->src_mip_level || info->src_layer != info->dst_layer, "GPU_OpBlit: blit of a subresource onto itself");   // :2792
+    GPU_REQUIRE_V(info->src_mip_level < s->mip_level_count && info->dst_mip_level < d->mip_level_count && info->src_layer < s->layer_count && info->dst_layer < d->layer_count,
+                  "GPU_OpBlit: bad subresource");
+    {   // whole-subresource 1:1 blit between equal formats (render.cpp:1158-1163: TAA result -> bloom_upscale_rt mip 0): a copy under either filter
+        uint32_t sw1 = mip_dim(s->width, info->src_mip_level), sh1 = mip_dim(s->height, info->src_mip_level);
+        uint32_t dw1 = mip_dim(d->width, info->dst_mip_level), dh1 = mip_dim(d->height, info->dst_mip_level);
+        bool whole = info->src_area[0].x == 0 && info->src_area[0].y == 0 && info->dst_area[0].x == 0 && info->dst_area[0].y == 0 &&
+                     (uint32_t)info->src_area[1].x == sw1 && (uint32_t)info->src_area[1].y == sh1 && (uint32_t)info->dst_area[1].x == dw1 && (uint32_t)info->dst_area[1].y == dh1;
+        if (whole && sw1 == dw1 && sh1 == dh1 && s->format == d->format && s->depth == 1 && d->depth == 1) {
+            Op op; op.kind = Op_Blit; op.name = "blit_1to1";
+            op.tex = (TextureImpl*)s; op.tex2 = (TextureImpl*)d; op.mip = info->src_mip_level; op.mip2 = info->dst_mip_level;
+            op.layer0 = info->src_layer; op.layer2 = info->dst_layer;
+            op.size = (uint64_t)sw1 * sh1 * ((TextureImpl*)s)->texel_bytes;
+            g->ops.push_back(op);
+            return;
+        }
+    }
     GPU_REQUIRE_V(s->format == GPU_Format_RGBA32F && d->format == GPU_Format_RGBA32F && info->filter == GPU_Filter_Linear, "GPU_OpBlit: RGBA32F linear blits only");
     GPU_REQUIRE_V(info->src_mip_level < s->mip_level_count && info->dst_mip_level < d->mip_level_count && info->src_layer < s->layer_count && info->dst_layer < d->layer_count,
                   "GPU_OpBlit: bad subresource");
@@ -1186,11 +1236,27 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
         GPU_DescriptorSet* s = op.set;
         GPU_RenderPass* rp = op.pass;
         TextureImpl* target = (TextureImpl*)rp->targets[0].texture;
-        if (op.gpipe->kernel == Kernel_TaaResolve || op.gpipe->kernel == Kernel_FinalPost) {
+        if (op.gpipe->kernel == Kernel_TaaResolve || op.gpipe->kernel == Kernel_FinalPost || op.gpipe->kernel == Kernel_BloomDown || op.gpipe->kernel == Kernel_BloomUp) {
             auto tex2d = [](TextureImpl* t, int fmt) { PbrkTex2D r; r.data = t->dev; r.format = fmt; r.width = (int)t->base.width; r.height = (int)t->base.height; return r; };
             auto out_fmt = [](GPU_Format f) {
                 return f == GPU_Format_RGBA16F ? PBRK_FMT_RGBA16F : (f == GPU_Format_RGBA32F ? PBRK_FMT_RGBA32F : (f == GPU_Format_RGBA8UN ? PBRK_FMT_RGBA8UN : PBRK_FMT_BGRA8UN));
             };
+            if (op.gpipe->kernel == Kernel_BloomDown || op.gpipe->kernel == Kernel_BloomUp) {
+                TextureImpl* in = named_slot(s, "TEX0")->tex;
+                PbrkBloomArgs a;
+                a.src.data = (char*)in->dev + in->mip_offset[op.mip]; a.src.format = PBRK_FMT_RGBA16F;
+                a.src.width = (int)mip_dim(in->base.width, op.mip); a.src.height = (int)mip_dim(in->base.height, op.mip);
+                a.dst = (char*)target->dev + target->mip_offset[op.mip2];
+                a.dst_width = (int)rp->desc.width; a.dst_height = (int)rp->desc.height;
+                int32_t lvl; memcpy(&lvl, op.push, 4); a.dst_mip_level = lvl;
+                a.upsample = op.gpipe->kernel == Kernel_BloomUp; a.blend_additive = op.gpipe->blend_additive;
+                a.y0 = (int)op.row0; a.y1 = (int)op.row1;
+                timed(g, a.upsample ? "K11.bloom_upsample" : "K10.bloom_downsample", ev_used, [&] {
+                    int rc = pbrk_bloom_pass(&a, st);
+                    if (rc != PBRK_OK) gpu_fail("bloom launch failed (%d)", rc);
+                });
+                return;
+            }
             if (op.gpipe->kernel == Kernel_TaaResolve) {
                 PbrkTaaArgs a;
                 a.lighting_result = tex2d(named_slot(s, "LIGHTING_RESULT")->tex, PBRK_FMT_RGBA16F);
@@ -1274,6 +1340,13 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
         return;
     }
     case Op_Blit: {
+        if (op.size) {                                                         // 1:1 copy of one layer
+            const void* src = (const char*)op.tex->dev + op.tex->mip_offset[op.mip] + op.size * op.layer0;
+            void* dst = (char*)op.tex2->dev + op.tex2->mip_offset[op.mip2] + op.size * op.layer2;
+            timed(g, op.name, ev_used, [&] { HIP_OK(hipMemcpyAsync(dst, src, op.size, hipMemcpyDeviceToDevice, st)); });
+            op.tex2->bordered_valid = false; op.tex2->lut_cells_valid = false;
+            return;
+        }
         uint32_t ns = mip_dim(op.tex->base.width, op.mip);
         size_t layer_bytes_s = (size_t)ns * ns * 16, layer_bytes_d = layer_bytes_s / 4;
         const void* src = (const char*)op.tex->dev + op.tex->mip_offset[op.mip] + layer_bytes_s * op.layer0;

@@ -98,6 +98,8 @@ __device__ __forceinline__ uint2 pack_half4(float r0, float r1, float r2) {
     return v;
 }
 
+__device__ __forceinline__ Rgba unpack_rgba16f(uint2 v) { return Rgba{h2f(v.x & 0xffff), h2f(v.x >> 16), h2f(v.y & 0xffff), h2f(v.y >> 16)}; }
+
 // buffer-addressed texel fetches: one 32-bit offset per load instead of a 64-bit address (textures are < 2 GiB, checked on the host)
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tex_rsrc(const PbrkTex2D& t, int texel_bytes) {
@@ -301,6 +303,72 @@ __global__ __launch_bounds__(256) void k_final_post_process_stream(PbrkFinalArgs
     }
 }
 
+// K10 / K11: bloom passes.  Column / row tap coordinates repeat (5 distinct offsets for the 13-tap downsample, 3 for the
+// tent), so the snapped bilinear split is done once per distinct offset and the taps index the results.
+struct BloomParams { PbrkBloomArgs a; float x_step, y_step, rcp_dw, rcp_dh; };
+
+template <bool kUp>
+__global__ __launch_bounds__(256) void k_bloom_pass(BloomParams P) {
+    const PbrkBloomArgs& A = P.a;
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int py = A.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= A.dst_width || py >= A.y1) return;
+    const int SW = A.src.width, SH = A.src.height;
+    const __amdgpu_buffer_rsrc_t rs = tex_rsrc(A.src, 8);
+    SharedRcp rw, rh;
+    rw.d = (float)A.dst_width; rw.r = P.rcp_dw; rh.d = (float)A.dst_height; rh.r = P.rcp_dh;
+    const float u = div_by((float)px + 0.5f, rw), v = div_by((float)py + 0.5f, rh);       // fs_uv (full-screen triangle)
+    constexpr int kOffs = kUp ? 3 : 5;                                                  // offsets -1..1 (x radius) or -2..2 (x texel)
+    int ci0[kOffs], ci1[kOffs], cj0[kOffs], cj1[kOffs]; float ca[kOffs], cb[kOffs];
+#pragma unroll
+    for (int k = 0; k < kOffs; ++k) {
+        const float off = (float)(k - kOffs / 2);
+        split_axis(u + off * P.x_step, SW, ci0[k], ci1[k], ca[k]);
+        split_axis(v + off * P.y_step, SH, cj0[k], cj1[k], cb[k]);
+    }
+    auto tap = [&](int kx, int ky, float* o) {
+        Rgba t00 = fetch_rgba16f(rs, SW, ci0[kx], cj0[ky]), t10 = fetch_rgba16f(rs, SW, ci1[kx], cj0[ky]);
+        Rgba t01 = fetch_rgba16f(rs, SW, ci0[kx], cj1[ky]), t11 = fetch_rgba16f(rs, SW, ci1[kx], cj1[ky]);
+        o[0] = lerpx(lerpx(t00.x, t10.x, ca[kx]), lerpx(t01.x, t11.x, ca[kx]), cb[ky]);
+        o[1] = lerpx(lerpx(t00.y, t10.y, ca[kx]), lerpx(t01.y, t11.y, ca[kx]), cb[ky]);
+        o[2] = lerpx(lerpx(t00.z, t10.z, ca[kx]), lerpx(t01.z, t11.z, ca[kx]), cb[ky]);
+    };
+    float r[3];
+    if (kUp) {                                                                          // bloom_upsample.glsl:43-58
+        float t[9][3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) tap(k % 3, k / 3, t[k]);                            // a b c / d e f / g h i
+        const float factor = A.dst_mip_level == 0 ? 0.06f : 1.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float sum = t[4][c] * 4.0f;
+            sum = sum + (((t[1][c] + t[3][c]) + t[5][c]) + t[7][c]) * 2.0f;
+            sum = sum + (((t[0][c] + t[2][c]) + t[6][c]) + t[8][c]);
+            r[c] = sum * factor / 16.0f;
+        }
+    } else {                                                                            // bloom_downsample.glsl:50-97
+        float t[13][3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) tap(2 * (k % 3), 2 * (k / 3), t[k]);                // a..i at offsets -2, 0, 2
+        tap(1, 1, t[9]); tap(3, 1, t[10]); tap(1, 3, t[11]); tap(3, 3, t[12]);          // j k l m at (+-1, +-1)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float sum = t[4][c] * 0.125f;
+            sum = sum + (((t[0][c] + t[2][c]) + t[6][c]) + t[8][c]) * 0.03125f;
+            sum = sum + (((t[1][c] + t[3][c]) + t[5][c]) + t[7][c]) * 0.0625f;
+            sum = sum + (((t[9][c] + t[10][c]) + t[11][c]) + t[12][c]) * 0.125f;
+            if (A.dst_mip_level == 1) sum = fminf(sum, 1.0f);
+            r[c] = sum;
+        }
+    }
+    uint2* o = (uint2*)A.dst + (size_t)py * A.dst_width + px;
+    if (A.blend_additive) {
+        Rgba d = unpack_rgba16f(*o);
+        r[0] = r[0] + d.x; r[1] = r[1] + d.y; r[2] = r[2] + d.z;
+    }
+    *o = pack_half4(r[0], r[1], r[2]);
+}
+
 bool tex_ok(const PbrkTex2D& t, int fmt) { return t.data && t.format == fmt && t.width > 0 && t.height > 0; }
 }  // namespace
 
@@ -343,5 +411,20 @@ extern "C" int pbrk_final_post_process(const PbrkFinalArgs* a, void* stream) {
     default: return PBRK_E_FORMAT;
     }
 #undef PBRK_FINAL_LAUNCH
+    return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+}
+
+extern "C" int pbrk_bloom_pass(const PbrkBloomArgs* a, void* stream) {
+    if (!a || !a->dst || a->dst_width < 1 || a->dst_height < 1 || a->y0 < 0 || a->y0 >= a->y1 || a->y1 > a->dst_height) return PBRK_E_ARG;
+    if (!tex_ok(a->src, PBRK_FMT_RGBA16F)) return PBRK_E_FORMAT;
+    if ((long long)a->src.width * a->src.height > (1ll << 27) || a->dst == a->src.data) return PBRK_E_ARG;
+    BloomParams p;
+    p.a = *a;
+    p.x_step = (a->upsample ? 1.5f : 1.0f) / (float)a->src.width;                       // radius / size, 1 / size (the shaders' x, y)
+    p.y_step = (a->upsample ? 1.5f : 1.0f) / (float)a->src.height;
+    p.rcp_dw = 1.0f / (float)a->dst_width; p.rcp_dh = 1.0f / (float)a->dst_height;
+    dim3 grid((a->dst_width + 63) / 64, (a->y1 - a->y0 + 3) / 4), block(256);
+    if (a->upsample) hipLaunchKernelGGL((k_bloom_pass<true>), grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_bloom_pass<false>), grid, block, 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }

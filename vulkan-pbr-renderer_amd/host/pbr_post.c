@@ -6,9 +6,10 @@
  *   render.cpp:456-501      final post-process pipeline + descriptor sets
  *   render.cpp:782-785      final pass onto the swapchain  -> here: onto an 8-bit "backbuffer" texture
  *   render.cpp:1131-1137, 1181-1187   the two full-screen draws per frame
- * The geometry raster pass that writes depth/velocity and the bloom chain between TAA and the final pass
- * (render.cpp:1139-1176) are outside this backend: callers upload velocity, and the final pass reads the TAA
- * result directly (its TEX0 slot is whatever texture is bound, final_post_process.glsl:28).
+ *   render.cpp:741-777, 340-454, 1139-1176   bloom: render targets with mips, 6 + 6 passes, clear + blit + additive upsamples
+ * The geometry raster pass that writes depth/velocity is outside this backend: callers upload velocity.  The final pass
+ * exists in two flavours: reading bloom_upscale_rt like the reference (PBR_RecordFinalPostProcessBloom, after
+ * PBR_RecordBloom) or reading the TAA result directly (its TEX0 slot is whatever texture is bound).
  */
 #include "pbr_host.h"
 
@@ -29,11 +30,30 @@ struct PBR_PostProcess {
     GPU_GraphicsPipeline* final_post_process_pipeline;
     GPU_DescriptorSet* final_post_process_desc_set[2];
     GPU_Texture* dummy;                  /* fills the slots a pass does not read (the reference's "unused descriptors") */
+    /* bloom (render.h:2 BLOOM_PASS_COUNT 6; fewer when the frame is too small to have that many mips) */
+    uint32_t bloom_pass_count;
+    GPU_Texture* bloom_downscale_rt; GPU_Texture* bloom_upscale_rt;
+    struct { GPU_RenderPass* render_pass[2]; GPU_GraphicsPipeline* pipeline[2]; GPU_DescriptorSet* desc_set[2]; } bloom_downsamples[6], bloom_upsamples[6];
+    GPU_DescriptorSet* final_post_process_bloom_desc_set[2];
 };
 
+static GPU_GraphicsPipeline* make_fullscreen_pipeline_blend(const char* path, size_t path_len, GPU_PipelineLayout* lo, GPU_RenderPass* rp, bool additive);
+static void fill_unused(PBR_PostProcess* pp, GPU_DescriptorSet* s) {
+    GPU_SetSamplerBinding(s, pp->sampler_b, GPU_SamplerLinearClamp());
+    GPU_SetTextureBinding(s, pp->prev_frame_b, pp->dummy);
+    GPU_SetTextureBinding(s, pp->depth_b, pp->dummy);
+    GPU_SetTextureBinding(s, pp->velocity_b, pp->dummy);
+    GPU_SetTextureBinding(s, pp->velocity_prev_b, pp->dummy);
+    GPU_SetTextureBinding(s, pp->lighting_result_b, pp->dummy);
+}
+
 static GPU_GraphicsPipeline* make_fullscreen_pipeline(const char* path, size_t path_len, GPU_PipelineLayout* lo, GPU_RenderPass* rp) {
+    return make_fullscreen_pipeline_blend(path, path_len, lo, rp, false);
+}
+static GPU_GraphicsPipeline* make_fullscreen_pipeline_blend(const char* path, size_t path_len, GPU_PipelineLayout* lo, GPU_RenderPass* rp, bool additive) {
     GPU_GraphicsPipelineDesc desc; memset(&desc, 0, sizeof desc);
     desc.layout = lo; desc.render_pass = rp;
+    desc.enable_blending = additive; desc.blending_mode_additive = additive;                  /* render.cpp:417-418 */
     desc.vs.glsl_debug_filepath.data = path; desc.vs.glsl_debug_filepath.length = path_len;
     desc.fs.glsl_debug_filepath = desc.vs.glsl_debug_filepath;
     GPU_GLSLErrorArray errors = {0};
@@ -100,11 +120,64 @@ PBR_PostProcess* PBR_MakePostProcess(const PBR_GBuffer* gb, uint32_t width, uint
         GPU_SetTextureBinding(s, pp->lighting_result_b, pp->dummy);
         GPU_FinalizeDescriptorSet(s);
     }
+    /* ---- bloom: render.cpp:741-777 (targets, passes), :340-454 (pipelines, descriptor sets) ---- */
+    static const char down_path[] = "../src/demo_pbr_renderer/shaders/bloom_downsample.glsl";
+    static const char up_path[] = "../src/demo_pbr_renderer/shaders/bloom_upsample.glsl";
+    GPU_TextureFlags bloom_flags = GPU_TextureFlag_RenderTarget | GPU_TextureFlag_HasMipmaps | GPU_TextureFlag_PerMipBinding;
+    pp->bloom_downscale_rt = GPU_MakeTexture(GPU_Format_RGBA16F, width / 2 ? width / 2 : 1, height / 2 ? height / 2 : 1, 1, bloom_flags, NULL);
+    pp->bloom_upscale_rt = GPU_MakeTexture(GPU_Format_RGBA16F, width, height, 1, bloom_flags, NULL);
+    pp->bloom_pass_count = pp->bloom_downscale_rt->mip_level_count < 6 ? pp->bloom_downscale_rt->mip_level_count : 6;
+    const uint32_t n = pp->bloom_pass_count;
+    for (int i = 0; i < 2; ++i) {
+        uint32_t w = width, h = height;
+        for (uint32_t step = 0; step < n; ++step) {                                                   /* render.cpp:751-763 */
+            GPU_TextureView targets[] = {{pp->bloom_downscale_rt, step}};
+            w /= 2; h /= 2;
+            GPU_RenderPassDesc pass_desc; memset(&pass_desc, 0, sizeof pass_desc);
+            pass_desc.width = w ? w : 1; pass_desc.height = h ? h : 1;
+            pass_desc.color_targets = targets; pass_desc.color_targets_count = 1;
+            pp->bloom_downsamples[step].render_pass[i] = GPU_MakeRenderPass(&pass_desc);
+            pp->bloom_downsamples[step].pipeline[i] = make_fullscreen_pipeline(down_path, sizeof down_path - 1, lo, pp->bloom_downsamples[step].render_pass[i]);
+            GPU_DescriptorSet* s = pp->bloom_downsamples[step].desc_set[i] = GPU_InitDescriptorSet(NULL, lo);   /* render.cpp:364-393 */
+            if (step == 0) GPU_SetTextureBinding(s, pp->tex0_b, pp->taa_output_rt[i]);
+            else GPU_SetTextureMipBinding(s, pp->tex0_b, pp->bloom_downscale_rt, step - 1);
+            fill_unused(pp, s);
+            GPU_FinalizeDescriptorSet(s);
+        }
+        w = width; h = height;
+        for (int step = (int)n - 1; step >= 0; --step) {                                              /* render.cpp:765-780 */
+            uint32_t dst_level = n - 1 - (uint32_t)step;
+            GPU_TextureView targets[] = {{pp->bloom_upscale_rt, dst_level}};
+            GPU_RenderPassDesc pass_desc; memset(&pass_desc, 0, sizeof pass_desc);
+            pass_desc.width = w ? w : 1; pass_desc.height = h ? h : 1;
+            pass_desc.color_targets = targets; pass_desc.color_targets_count = 1;
+            pp->bloom_upsamples[step].render_pass[i] = GPU_MakeRenderPass(&pass_desc);
+            w /= 2; h /= 2;
+            pp->bloom_upsamples[step].pipeline[i] = make_fullscreen_pipeline_blend(up_path, sizeof up_path - 1, lo, pp->bloom_upsamples[step].render_pass[i], true);
+            GPU_DescriptorSet* s = pp->bloom_upsamples[step].desc_set[i] = GPU_InitDescriptorSet(NULL, lo);     /* render.cpp:422-451 */
+            if (step == 0) GPU_SetTextureMipBinding(s, pp->tex0_b, pp->bloom_downscale_rt, n - 1);
+            else GPU_SetTextureMipBinding(s, pp->tex0_b, pp->bloom_upscale_rt, n - (uint32_t)step);
+            fill_unused(pp, s);
+            GPU_FinalizeDescriptorSet(s);
+        }
+        GPU_DescriptorSet* s = pp->final_post_process_bloom_desc_set[i] = GPU_InitDescriptorSet(NULL, lo);      /* render.cpp:475-501 */
+        GPU_SetTextureBinding(s, pp->tex0_b, pp->bloom_upscale_rt);
+        fill_unused(pp, s);
+        GPU_FinalizeDescriptorSet(s);
+    }
     return pp;
 }
 
 void PBR_DestroyPostProcess(PBR_PostProcess* pp) {
     if (!pp) return;
+    for (uint32_t step = 0; step < pp->bloom_pass_count; ++step)                                      /* render.cpp:890-902, 921-926 */
+        for (int i = 0; i < 2; ++i) {
+            GPU_DestroyGraphicsPipeline(pp->bloom_downsamples[step].pipeline[i]); GPU_DestroyDescriptorSet(pp->bloom_downsamples[step].desc_set[i]);
+            GPU_DestroyGraphicsPipeline(pp->bloom_upsamples[step].pipeline[i]); GPU_DestroyDescriptorSet(pp->bloom_upsamples[step].desc_set[i]);
+            GPU_DestroyRenderPass(pp->bloom_downsamples[step].render_pass[i]); GPU_DestroyRenderPass(pp->bloom_upsamples[step].render_pass[i]);
+        }
+    for (int i = 0; i < 2; ++i) GPU_DestroyDescriptorSet(pp->final_post_process_bloom_desc_set[i]);
+    GPU_DestroyTexture(pp->bloom_downscale_rt); GPU_DestroyTexture(pp->bloom_upscale_rt);
     for (int i = 0; i < 2; ++i) {                                                        /* render.cpp:885-888, 904-906 */
         GPU_DestroyGraphicsPipeline(pp->taa_resolve_pipeline[i]);
         GPU_DestroyDescriptorSet(pp->taa_resolve_descriptor_set[i]);
@@ -149,6 +222,52 @@ void PBR_RecordFinalPostProcess(PBR_PostProcess* pp, GPU_Graph* graph, uint32_t 
     uint32_t frame_idx_mod2 = frame_idx % 2;
     GPU_OpPrepareRenderPass(graph, pp->final_post_process_render_pass);                   /* render.cpp:1181-1187 */
     uint32_t final_pp_draw_params = GPU_OpPrepareDrawParams(graph, pp->final_post_process_pipeline, pp->final_post_process_desc_set[frame_idx_mod2]);
+    GPU_OpBeginRenderPass(graph);
+    GPU_OpBindDrawParams(graph, final_pp_draw_params);
+    GPU_OpDraw(graph, 3, 1, 0, 0);
+    GPU_OpEndRenderPass(graph);
+}
+
+GPU_Texture* PBR_PostBloomDownscale(PBR_PostProcess* pp) { return pp->bloom_downscale_rt; }
+GPU_Texture* PBR_PostBloomUpscale(PBR_PostProcess* pp) { return pp->bloom_upscale_rt; }
+uint32_t PBR_PostBloomPassCount(const PBR_PostProcess* pp) { return pp->bloom_pass_count; }
+
+void PBR_RecordBloom(PBR_PostProcess* pp, GPU_Graph* graph, uint32_t frame_idx) {
+    uint32_t frame_idx_mod2 = frame_idx % 2;
+    const uint32_t n = pp->bloom_pass_count;
+    for (uint32_t step = 0; step < n; step++) {                                           /* render.cpp:1141-1152 */
+        GPU_OpPrepareRenderPass(graph, pp->bloom_downsamples[step].render_pass[frame_idx_mod2]);
+        uint32_t draw_params = GPU_OpPrepareDrawParams(graph, pp->bloom_downsamples[step].pipeline[frame_idx_mod2], pp->bloom_downsamples[step].desc_set[frame_idx_mod2]);
+        GPU_OpBeginRenderPass(graph);
+        uint32_t dst_mip_level = step + 1;
+        GPU_OpPushGraphicsConstants(graph, pp->layout, &dst_mip_level, sizeof(dst_mip_level));
+        GPU_OpBindDrawParams(graph, draw_params);
+        GPU_OpDraw(graph, 3, 1, 0, 0);
+        GPU_OpEndRenderPass(graph);
+    }
+    GPU_OpClearColorF(graph, pp->bloom_upscale_rt, GPU_MIP_LEVEL_ALL, 0.f, 0.f, 0.f, 0.f); /* render.cpp:1156 */
+    GPU_OpBlitInfo blit; memset(&blit, 0, sizeof blit);                                    /* render.cpp:1158-1163 */
+    blit.src_area[1].x = (int)pp->width; blit.src_area[1].y = (int)pp->height; blit.src_area[1].z = 1;
+    blit.dst_area[1] = blit.src_area[1];
+    blit.src_texture = pp->taa_output_rt[frame_idx_mod2];
+    blit.dst_texture = pp->bloom_upscale_rt;
+    GPU_OpBlit(graph, &blit);
+    for (uint32_t step = 0; step < n; step++) {                                           /* render.cpp:1165-1176 */
+        GPU_OpPrepareRenderPass(graph, pp->bloom_upsamples[step].render_pass[frame_idx_mod2]);
+        uint32_t draw_params = GPU_OpPrepareDrawParams(graph, pp->bloom_upsamples[step].pipeline[frame_idx_mod2], pp->bloom_upsamples[step].desc_set[frame_idx_mod2]);
+        GPU_OpBeginRenderPass(graph);
+        uint32_t dst_mip_level = n - step - 1;
+        GPU_OpPushGraphicsConstants(graph, pp->layout, &dst_mip_level, sizeof(dst_mip_level));
+        GPU_OpBindDrawParams(graph, draw_params);
+        GPU_OpDraw(graph, 3, 1, 0, 0);
+        GPU_OpEndRenderPass(graph);
+    }
+}
+
+void PBR_RecordFinalPostProcessBloom(PBR_PostProcess* pp, GPU_Graph* graph, uint32_t frame_idx) {
+    uint32_t frame_idx_mod2 = frame_idx % 2;
+    GPU_OpPrepareRenderPass(graph, pp->final_post_process_render_pass);                   /* render.cpp:1181-1187, TEX0 = bloom_upscale_rt */
+    uint32_t final_pp_draw_params = GPU_OpPrepareDrawParams(graph, pp->final_post_process_pipeline, pp->final_post_process_bloom_desc_set[frame_idx_mod2]);
     GPU_OpBeginRenderPass(graph);
     GPU_OpBindDrawParams(graph, final_pp_draw_params);
     GPU_OpDraw(graph, 3, 1, 0, 0);

@@ -181,6 +181,8 @@ PROTOTYPES = {
     "PBR_RecordLightingPass": (None, [VP, VP, C.POINTER(PBR_Globals), U32, U32]),
     "PBR_MakePostProcess": (VP, [C.POINTER(PBR_GBuffer), U32, U32, C.c_int]), "PBR_DestroyPostProcess": (None, [VP]),
     "PBR_PostVelocity": (TexP, [VP, U32]), "PBR_PostTaaOutput": (TexP, [VP, U32]), "PBR_PostBackbuffer": (TexP, [VP]),
+    "PBR_RecordBloom": (None, [VP, VP, U32]), "PBR_RecordFinalPostProcessBloom": (None, [VP, VP, U32]),
+    "PBR_PostBloomDownscale": (TexP, [VP]), "PBR_PostBloomUpscale": (TexP, [VP]), "PBR_PostBloomPassCount": (U32, [VP]),
     "PBR_RecordTaaResolve": (None, [VP, VP, U32]), "PBR_RecordTaaResolveRows": (None, [VP, VP, U32, U32, U32]), "PBR_RecordFinalPostProcess": (None, [VP, VP, U32]),
     "PBR_MakeLightgrid": (VP, [U32]), "PBR_DestroyLightgrid": (None, [VP]), "PBR_LightgridTexture": (TexP, [VP]),
     "PBR_LightgridSweepDirection": (U32, [VP]), "PBR_RecordLightgridClear": (None, [VP, VP]),
@@ -193,6 +195,7 @@ PROTOTYPES = {
     "pbrk_host_irradiance_table": (C.c_int, [C.c_int, VP]),
     "pbrk_mip_chain": (C.c_int, [VP, C.c_int, C.c_int, VP]), "pbrk_box_downsample": (C.c_int, [VP, C.c_int, VP, C.c_int, VP]),
     "pbrk_border_build": (C.c_int, [VP, VP, C.c_int, C.c_int, VP]),
+    "pbrk_bloom_pass": (C.c_int, [VP, VP]),
     "pbrk_taa_resolve": (C.c_int, [VP, VP]), "pbrk_final_post_process": (C.c_int, [VP, VP]),
     "pbrk_lightgrid_sweep": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "pbrk_brdf_lut": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, C.c_int, VP]),
