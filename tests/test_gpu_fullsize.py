@@ -194,7 +194,8 @@ def test_c_demo_hdr_file_end_to_end(gpu, tmp_path):
     hdr = tmp_path / "cube_strip.hdr"
     hdr.write_bytes(synth.env_to_hdr_strip(env, rle=True))
     exe = os.path.join(pbrhip.PKG_ROOT, "pbr_demo")
-    out = subprocess.run([exe, str(hdr), "32", "256", "64", "16", "320", "180"], capture_output=True, text=True, timeout=300)
+    ppm = tmp_path / "frame.ppm"
+    out = subprocess.run([exe, str(hdr), "32", "256", "64", "16", "320", "180", str(ppm)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     kv = {}
     for line in out.stdout.splitlines():
@@ -223,6 +224,50 @@ def test_c_demo_hdr_file_end_to_end(gpu, tmp_path):
     assert "specular_mip3_sum" not in kv                      # reference stop rule: size < 16 (render.cpp:566)
     assert kv["lut_bits_sum"] == fsum(pbrhip.read_mip(maps.brdf_lut, 0).view(np.uint16))
     assert kv["lit_bits_sum"] > 0
+
+    # the per-frame chain of the demo (lighting -> TAA -> bloom -> tone map, three frames) and its light-grid sweeps, from Python
+    W, H = 320, 180
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), W, H, pbrhip.Format_RGBA16F)
+    plane = lambda rgba: np.broadcast_to(np.array(rgba, np.uint8), (H, W, 4)).copy()
+    pbrhip.upload_mip(gb.base_color, 0, plane((255, 195, 86, 255))); pbrhip.upload_mip(gb.normal, 0, plane((128, 128, 255, 255)))
+    pbrhip.upload_mip(gb.orm, 0, plane((255, 90, 255, 255))); pbrhip.upload_mip(gb.emissive, 0, plane((0, 0, 0, 255)))
+    depth = np.ones((H, W), np.float32); depth[H // 2:] = 0.998
+    pbrhip.upload_mip(gb.depth, 0, depth)
+    lp = L.PBR_MakeLightingPass(C.byref(gb), C.byref(maps), W, H)
+    pp = L.PBR_MakePostProcess(C.byref(gb), W, H, pbrhip.Format_RGBA8UN)
+    g = L.GPU_MakeGraph()
+    glob = pbrhip.fill_globals((0.0, 0.0, 5.0), aspect=W / H, frame_idx=0)
+    L.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    assert kv["lit_bits_sum"] == fsum(pbrhip.read_mip(gb.lighting_result, 0).view(np.uint16))
+    for frame in range(3):
+        glob = pbrhip.fill_globals((0.0, 0.0, 5.0), aspect=W / H, frame_idx=frame)
+        L.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
+        L.PBR_RecordTaaResolve(pp, g, frame); L.PBR_RecordBloom(pp, g, frame); L.PBR_RecordFinalPostProcessBloom(pp, g, frame)
+        L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    L.GPU_DestroyGraph(g)
+    assert kv["taa_bits_sum"] == fsum(pbrhip.read_mip(L.PBR_PostTaaOutput(pp, 0), 0).view(np.uint16))
+    assert kv["bloom_bits_sum"] == fsum(pbrhip.read_mip(L.PBR_PostBloomUpscale(pp), 0).view(np.uint16))
+    bb = pbrhip.read_mip(L.PBR_PostBackbuffer(pp), 0)
+    assert kv["frame_bytes_sum"] == fsum(bb)
+    raw = ppm.read_bytes()
+    head = b"P6\n320 180\n255\n"
+    assert raw.startswith(head) and len(raw) == len(head) + W * H * 3
+    assert np.array_equal(np.frombuffer(raw[len(head):], np.uint8).reshape(H, W, 3), bb[..., :3])
+    assert bb[: H // 2, :, :3].mean() > 30 and bb[H // 2:, :, :3].mean() > 10           # a visible sky and a lit floor
+    lg = L.PBR_MakeLightgrid(128)
+    scene = np.zeros((128, 128, 128, 4), np.uint16)
+    scene[:4] = [0x3800, 0x3400, 0x3000, 0x3C00]
+    g = L.GPU_MakeGraph()
+    L.PBR_RecordLightgridClear(lg, g)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    pbrhip.upload_mip(L.PBR_LightgridTexture(lg), 0, scene)
+    for _ in range(3):
+        L.PBR_RecordLightgridSweep(lg, g)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g); L.GPU_DestroyGraph(g)
+    assert kv["lightgrid_bits_sum"] == fsum(pbrhip.read_mip(L.PBR_LightgridTexture(lg), 0).view(np.uint16))
+    L.PBR_DestroyLightgrid(lg); L.PBR_DestroyPostProcess(pp); L.PBR_DestroyLightingPass(lp); L.PBR_DestroyGBuffer(C.byref(gb))
     L.PBR_DestroyIBLMaps(C.byref(maps)); L.GPU_DestroyTexture(tex)
 
 

@@ -2,12 +2,14 @@
  * pbr_demo.c -- headless C driver of the hot path through the GPU_* boundary (what main.cpp:35-51 +
  * HotreloadShaders + BuildRenderCommands do for this path, without window / mesh import / raster passes).
  *
- *   pbr_demo <cube_strip.hdr> [irradiance_size lut_size specular_size min_size [width height]]
+ *   pbr_demo <cube_strip.hdr> [irradiance_size lut_size specular_size min_size [width height [frame.ppm]]]
  *
  * Loads a vertical-strip HDR cube (asset_import.cpp:17-27), runs the IBL precompute (render.cpp:505-619),
- * shades a flat synthetic G-buffer (a metallic floor under the sky), and prints fp64 checksums of every map plus
- * HIP-event timings per kernel, one "key value" pair per line, so that a test can compare it with the same
- * sequence driven from another language.
+ * shades a flat synthetic G-buffer (a metallic floor under the sky), then runs three frames of the per-frame chain
+ * lighting -> TAA resolve -> bloom -> tone map (render.cpp:1119-1187) plus the light-grid sweep (render.cpp:1061-1072),
+ * and prints fp64 checksums of every map / frame plus HIP-event timings per kernel, one "key value" pair per line, so
+ * that a test can compare it with the same sequence driven from another language.  With a last argument the 8-bit
+ * frame is written as a binary PPM.
  */
 #include "pbr_host.h"
 
@@ -96,6 +98,67 @@ int main(int argc, char** argv) {
     for (uint32_t i = 0; i < GPUX_GraphTimedOpCount(graph); ++i)
         printf("time_ms %s %.6f\n", GPUX_GraphTimedOpName(graph, i), GPUX_GraphTimedOpMs(graph, i));
     printf("lit_bits_sum %.9e\n", checksum_texture_mip(gb.lighting_result, 0, 0));
+
+    /* ---- per-frame chain: lighting -> TAA -> bloom -> final, three frames (velocity buffers stay zero: a still camera) ---- */
+    PBR_PostProcess* pp = PBR_MakePostProcess(&gb, width, height, GPU_Format_RGBA8UN);
+    for (uint32_t frame = 0; frame < 3; ++frame) {
+        PBR_FillGlobals(&globals, pos, NULL, 75.f, (float)width / (float)height, 0.02f, 10000.f, 56.5f, 97.f, frame);
+        PBR_RecordLightingPass(lp, graph, &globals, 0, 0);                   /* render.cpp:1119-1127 */
+        PBR_RecordTaaResolve(pp, graph, frame);                              /* render.cpp:1131-1137 */
+        PBR_RecordBloom(pp, graph, frame);                                   /* render.cpp:1139-1176 */
+        PBR_RecordFinalPostProcessBloom(pp, graph, frame);                   /* render.cpp:1181-1187 */
+        GPU_GraphSubmit(graph);
+        GPU_GraphWait(graph);
+    }
+    for (uint32_t i = 0; i < GPUX_GraphTimedOpCount(graph); ++i)
+        printf("time_ms %s %.6f\n", GPUX_GraphTimedOpName(graph, i), GPUX_GraphTimedOpMs(graph, i));
+    printf("taa_bits_sum %.9e\n", checksum_texture_mip(PBR_PostTaaOutput(pp, 0), 0, 0));
+    printf("bloom_bits_sum %.9e\n", checksum_texture_mip(PBR_PostBloomUpscale(pp), 0, 0));
+    {
+        GPU_Texture* bb = PBR_PostBackbuffer(pp);
+        uint32_t bytes = (uint32_t)GPUX_TextureMipBytes(bb, 0);
+        GPU_Buffer* buf = GPU_MakeBuffer(bytes, GPU_BufferFlag_CPU, NULL);
+        GPU_Graph* g = GPU_MakeGraph();
+        GPU_OpCopyTextureToBuffer(g, bb, buf);
+        GPU_GraphSubmit(g); GPU_GraphWait(g);
+        const uint8_t* px = (const uint8_t*)buf->data;
+        double sum = 0.0;
+        for (uint32_t i = 0; i < bytes; ++i) sum += (double)px[i];
+        printf("frame_bytes_sum %.9e\n", sum);
+        if (argc > 8) {                                                      /* binary PPM, rows top-down as rendered */
+            FILE* f = fopen(argv[8], "wb");
+            if (!f) { perror(argv[8]); return 1; }
+            fprintf(f, "P6\n%u %u\n255\n", width, height);
+            for (uint32_t i = 0; i < width * height; ++i) fwrite(px + 4 * i, 1, 3, f);
+            fclose(f);
+        }
+        GPU_DestroyGraph(g); GPU_DestroyBuffer(buf);
+    }
+
+    /* ---- voxel light grid: clear, a ground slab of lit voxels, three sweeps (directions y, z, x) ---- */
+    {
+        PBR_Lightgrid* lg = PBR_MakeLightgrid(128);                          /* render.cpp:678 */
+        GPU_Texture* grid = PBR_LightgridTexture(lg);
+        uint32_t bytes = (uint32_t)GPUX_TextureMipBytes(grid, 0);
+        uint16_t* vox = (uint16_t*)calloc(bytes, 1);
+        for (uint32_t z = 0; z < 4; ++z)                                     /* RGBA16F: (0.5, 0.25, 0.125, 1) in the four lowest layers */
+            for (uint32_t i = 0; i < 128 * 128; ++i) {
+                uint16_t* v = vox + ((size_t)z * 128 * 128 + i) * 4;
+                v[0] = 0x3800; v[1] = 0x3400; v[2] = 0x3000; v[3] = 0x3c00;
+            }
+        GPU_Buffer* up = GPU_MakeBuffer(bytes, GPU_BufferFlag_CPU, vox);
+        GPU_Graph* g = GPU_MakeGraph();
+        PBR_RecordLightgridClear(lg, g);                                     /* render.cpp:1028 */
+        GPUX_OpCopyBufferToTextureMip(g, up, 0, grid, 0);
+        for (int k = 0; k < 3; ++k) PBR_RecordLightgridSweep(lg, g);         /* render.cpp:1061-1072 */
+        GPU_GraphSubmit(g); GPU_GraphWait(g);
+        for (uint32_t i = 0; i < GPUX_GraphTimedOpCount(g); ++i)
+            printf("time_ms %s %.6f\n", GPUX_GraphTimedOpName(g, i), GPUX_GraphTimedOpMs(g, i));
+        printf("lightgrid_bits_sum %.9e\n", checksum_texture_mip(grid, 0, 0));
+        GPU_DestroyGraph(g); GPU_DestroyBuffer(up); free(vox);
+        PBR_DestroyLightgrid(lg);
+    }
+    PBR_DestroyPostProcess(pp);
 
     GPU_DestroyGraph(graph);
     PBR_DestroyLightingPass(lp);
