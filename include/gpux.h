@@ -38,7 +38,8 @@ GPU_API void GPUX_OpDispatchRows(GPU_Graph* graph, uint32_t face0, uint32_t face
 GPU_API void GPUX_OpDispatchLines(GPU_Graph* graph, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1);
 
 /* ---- shade pass controls ---- */
-enum { GPUX_Shade_IBL = 1 << 0, GPUX_Shade_LightShafts = 1 << 1 };
+enum { GPUX_Shade_IBL = 1 << 0, GPUX_Shade_LightShafts = 1 << 1,
+       GPUX_Shade_SunShadows = 1 << 2 /* SUN_DEPTH_MAP: 4-tap PCF sun shadow + shaft visibility (lighting_pass.glsl:594-608, 646) */ };
 GPU_API void GPUX_SetShadeFlags(GPU_GraphicsPipeline* pipeline, int flags);    /* default GPUX_Shade_IBL */
 /* full-screen draw restricted to rows [row0,row1) (screen-band sharding) */
 GPU_API void GPUX_OpDrawRows(GPU_Graph* graph, uint32_t row0, uint32_t row1);

@@ -103,6 +103,9 @@ void PBR_DestroyGBuffer(PBR_GBuffer* gb);
 
 typedef struct PBR_LightingPass PBR_LightingPass;
 PBR_LightingPass* PBR_MakeLightingPass(const PBR_GBuffer* gb, const PBR_IBLMaps* maps, uint32_t width, uint32_t height);
+/* the same with the sun depth map of the shadow pass bound to SUN_DEPTH_MAP (render.cpp:676, :863; D32F); NULL = 1x1 stand-in.
+ * GPUX_SetShadeFlags(PBR_LightingPipeline(lp), ... | GPUX_Shade_SunShadows) makes the pass read it. */
+PBR_LightingPass* PBR_MakeLightingPassEx(const PBR_GBuffer* gb, const PBR_IBLMaps* maps, uint32_t width, uint32_t height, GPU_Texture* sun_depth_map);
 void PBR_DestroyLightingPass(PBR_LightingPass* lp);
 GPU_Buffer* PBR_LightingGlobalsBuffer(PBR_LightingPass* lp);           /* persistently mapped (render.cpp:675) */
 GPU_GraphicsPipeline* PBR_LightingPipeline(PBR_LightingPass* lp);

@@ -43,7 +43,8 @@ enum {                      /* output formats understood by the kernels */
 
 enum {                      /* shade flags (reference lighting_pass.glsl sub-blocks) */
     PBRK_SHADE_IBL = 1 << 0,     /* ambient = irradiance(N); spec = prefiltered(R, rough*4)  (:690, :699) */
-    PBRK_SHADE_SHAFTS = 1 << 1   /* light-shaft loop with visibility == 1 (:622-651) */
+    PBRK_SHADE_SHAFTS = 1 << 1,  /* light-shaft loop (:622-651); visibility == 1 unless PBRK_SHADE_SHADOWS */
+    PBRK_SHADE_SHADOWS = 1 << 2  /* sun shadow: 4 PCF taps of the sun depth map (:594-608) + shaft visibility (:646) */
 };
 
 /* sizes / offsets of the pyramid layouts, in float4 texels */
@@ -132,6 +133,8 @@ typedef struct PbrkShadeArgs {
     const void* prefiltered_cells;
     int prefiltered_cells_first;
     const void* lut_cells;              /* uint4 [(S+1)][(S+1)]: {t00,t10,t01,t11} half2, tap origin (-1,-1), clamp-to-edge */
+    const void* sun_depth;              /* float [sun_depth_h][sun_depth_w] (SUN_DEPTH_MAP, render.cpp:676); PBRK_SHADE_SHADOWS */
+    int sun_depth_w, sun_depth_h;
     void* out;                          /* half4 or float4 [H][W] */
     int out_format;                     /* PBRK_FMT_RGBA16F / PBRK_FMT_RGBA32F */
     int flags;                          /* PBRK_SHADE_* */

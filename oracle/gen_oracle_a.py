@@ -99,6 +99,7 @@ extern "C" {
 vec4 (*shim_cube_lookup)(int, vec3, float);
 vec4 (*shim_tex2d_lookup)(int, vec2, float);
 ivec2 (*shim_tex2d_size)(int);
+float (*shim_shadow_lookup)(int, vec3);
 static std::vector<float> load_f32(const char* path) {
     FILE* f = fopen(path, "rb"); if (!f) { perror(path); exit(2); }
     fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
@@ -169,6 +170,8 @@ static vec4 cube_cb(int id, vec3 d, float lod) {
     if (g_mode == 1) { if (id == 20) return 0.5f * env(d); return env(d) * (1.0f - 0.1f * lod); }
     return env(d);
 }
+static std::vector<float> g_sun; static OrcTex2D g_sun_tex;
+static float shadow_cb(int, vec3 p) { return orc_shadow_sample(&g_sun_tex, p.x, p.y, p.z); }
 static vec4 u8v(const unsigned char* p) { return vec4(p[0] / 255.0f, p[1] / 255.0f, p[2] / 255.0f, p[3] / 255.0f); }
 static vec4 tex2d_cb(int id, vec2 uv, float) {
     switch (id) {
@@ -199,6 +202,13 @@ int main(int argc, char** argv) {
     FILE* f = fopen(argv[5], "rb"); fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
     std::vector<PixelRec> px(n / sizeof(PixelRec)); if (fread(px.data(), 1, n, f) != (size_t)n) return 3; fclose(f);
     shim_cube_lookup = cube_cb; shim_tex2d_lookup = tex2d_cb;
+    if (const char* sun = getenv("ORACLE_A_SUN_DEPTH")) {            // "path,w,h": enables the shadow-map sampler (R32F)
+        char path[512]; int sw = 0, sh = 0;
+        if (sscanf(sun, "%511[^,],%d,%d", path, &sw, &sh) != 3) return 4;
+        g_sun = load_f32(path);
+        g_sun_tex.data = g_sun.data(); g_sun_tex.format = ORC_TEX_R32F; g_sun_tex.width = sw; g_sun_tex.height = sh;
+        shim_shadow_lookup = shadow_cb;
+    }
     std::vector<float> out(px.size() * 4);
     for (size_t i = 0; i < px.size(); i++) {
         g_px = px[i];
@@ -325,14 +335,19 @@ PIXEL_DT = np.dtype([("x", "<i4"), ("y", "<i4"), ("base", "u1", 4), ("nrm", "u1"
                      ("emi", "u1", 4), ("depth", "<f4")])
 
 
-def run_lighting(exe, mode, W, H, globals_bytes, pixels, extra=()):
+def run_lighting(exe, mode, W, H, globals_bytes, pixels, extra=(), sun_depth=None):
     gp = os.path.join(SCRATCH, "globals.bin")
     pp = os.path.join(SCRATCH, f"pixels_{os.getpid()}.bin")
     op = os.path.join(SCRATCH, f"lit_{os.getpid()}.bin")
     with open(gp, "wb") as f:
         f.write(globals_bytes)
     pixels.tofile(pp)
-    subprocess.check_call([exe, str(mode), str(W), str(H), gp, pp, op] + [str(e) for e in extra])
+    env = dict(os.environ)
+    if sun_depth is not None:
+        sp = os.path.join(SCRATCH, f"sun_{os.getpid()}.bin")
+        np.ascontiguousarray(sun_depth, np.float32).tofile(sp)
+        env["ORACLE_A_SUN_DEPTH"] = f"{sp},{sun_depth.shape[1]},{sun_depth.shape[0]}"
+    subprocess.check_call([exe, str(mode), str(W), str(H), gp, pp, op] + [str(e) for e in extra], env=env)
     return np.fromfile(op, dtype=np.float32).reshape(-1, 4)
 
 
@@ -351,6 +366,24 @@ def sweep_inputs(seed, shape_dhw):
     dark = rng.random((d, h, w)) < 0.05
     g[dark & ~occ, :3] = 0
     return g
+
+
+def gen_shadow(meta):
+    """Live lighting shader with its light shafts and the sun-shadow block reading a synthetic sun depth map
+    (lighting_pass.glsl:594-608, 622-651); same 2304 pixels and Globals as the lighting tile; voxel GI stays 0."""
+    import pbr_oracle as O
+    from pbrhip import synth
+    gbuf = np.load(os.path.join(GOLDEN, "ref_globals_default.npy"))
+    gbytes = np.concatenate([gbuf, np.zeros(2, np.float32)]).astype(np.float32).tobytes()[:552]
+    tile = np.load(os.path.join(GOLDEN, "oracle_a_lighting_tile_inputs.npy"))
+    sun = synth.synth_sun_depth(256, 0x5EED00E0)
+    exe = build("lighting_live_shaft", "lighting_pass.glsl", DRIVER_LIGHTING, lighting_variant="live_shaft")
+    out = run_lighting(exe, 0, 1920, 1080, gbytes, tile, sun_depth=sun)
+    np.save(os.path.join(GOLDEN, "oracle_a_lighting_tile_live_shadow.npy"), out)
+    lit = np.load(os.path.join(GOLDEN, "oracle_a_lighting_tile_live_shaft.npy"))
+    print("shadow variant: pixels darker than the unshadowed variant:", int((out[:, :3].sum(1) < lit[:, :3].sum(1) - 1e-6).sum()), "of", len(out))
+    meta["lighting_tile_shadow"] = {"file": "oracle_a_lighting_tile_live_shadow.npy", "sun_depth": "pbrhip.synth.synth_sun_depth(256, 0x5EED00E0)",
+                                    "note": "variant live_shaft + SUN_DEPTH_MAP sampled with the oracle's PCF sampler"}
 
 
 def gen_sweep(meta):
@@ -471,7 +504,7 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--only":       # regenerate one group, keep the rest of the metadata
         with open(os.path.join(GOLDEN, "oracle_a_meta.json")) as f:
             meta = json.load(f)
-        {"sweep": gen_sweep, "post": gen_post, "bloom": gen_bloom}[sys.argv[2]](meta)
+        {"sweep": gen_sweep, "post": gen_post, "bloom": gen_bloom, "shadow": gen_shadow}[sys.argv[2]](meta)
         with open(os.path.join(GOLDEN, "oracle_a_meta.json"), "w") as f:
             json.dump(meta, f, indent=1)
         return
@@ -582,6 +615,7 @@ def main():
         np.save(os.path.join(GOLDEN, f"oracle_a_lighting_tile_{variant}.npy"), out)
     meta["lighting_tile"] = {"inputs": "oracle_a_lighting_tile_inputs.npy", "seed": 0x5EED00AC, "count": n}
 
+    gen_shadow(meta)
     gen_sweep(meta)
     gen_post(meta)
     gen_bloom(meta)

@@ -201,7 +201,8 @@ inline vec4 texture(H_2d h, vec2 uv) { return shim_tex2d_lookup(h.id, uv, 0.0f);
 extern ivec2 (*shim_tex2d_size)(int id);
 inline ivec2 textureSize(H_2d h, int) { return shim_tex2d_size(h.id); }
 inline vec4 texture(H_3d, vec3) { return vec4(0.0f); }         // LIGHTGRID == 0 (out of scope)
-inline float texture(H_shadow, vec3) { return 1.0f; }          // shadow map == fully lit (out of scope)
+extern float (*shim_shadow_lookup)(int id, vec3 uv_ref);       // NULL: shadow map == fully lit
+inline float texture(H_shadow h, vec3 p) { return shim_shadow_lookup ? shim_shadow_lookup(h.id, p) : 1.0f; }
 
 inline ivec2 imageSize(const imageCube& im) { return ivec2(im.size, im.size); }
 inline ivec2 imageSize(const image2D& im) { return ivec2(im.size, im.size); }

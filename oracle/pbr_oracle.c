@@ -719,8 +719,24 @@ void orc_shade(const OrcGlobals* g, const OrcShadeInputs* in, int flags,
             float noise_2 = fractf_(ign(fcx + 90.0f, fcy + 20.0f) + noise_offset);
             float noise_3 = fractf_(ign(fcx + 522.0f, fcy + 55.0f) + noise_offset);
 
-            /* :594-608 shadow map is out of scope: shadow = 1 */
+            /* :594-608 sun shadow: 4 PCF taps around a noise-jittered position (shadow = 1 without ORC_SHADE_SHADOWS) */
             float shadow = 1.0f;
+            float p0s[4] = {0, 0, 0, 0};                                                  /* p0_sun_space */
+            if (flags & (ORC_SHADE_SHADOWS | ORC_SHADE_SHAFTS)) {
+                float sp4[4] = {p0_world.x + Nn.x * 0.1f, p0_world.y + Nn.y * 0.1f, p0_world.z + Nn.z * 0.1f, 1.0f};   /* :596 */
+                mat4_mul_v4(g->sun_space_from_world, sp4, p0s);                          /* :597 */
+            }
+            if (flags & ORC_SHADE_SHADOWS) {
+                const float px_size = 1.0f / 2048.0f;                                    /* :594 */
+                float sx = p0s[0] * 0.5f + 0.5f, sy = p0s[1] * 0.5f + 0.5f, sz = p0s[2]; /* :598 */
+                sx = sx + (2.0f * (noise_2 - 0.5f)) * px_size;                           /* :600 */
+                sy = sy + (2.0f * (noise_1 - 0.5f)) * px_size;
+                static const float ox[4] = {0.75f, -0.25f, 0.25f, -0.75f}, oy[4] = {0.25f, 0.75f, -0.75f, -0.25f};
+                float acc = 0.0f;
+                for (int k = 0; k < 4; ++k)                                              /* :604-608 */
+                    acc = acc + orc_shadow_sample(&in->sun_depth_map, sx + ox[k] * px_size, sy + oy[k] * px_size, sz + 0.0f * px_size);
+                shadow = acc * 0.25f;
+            }
 
             /* :612-613 */
             v3 cam = V3(g->camera_pos[0], g->camera_pos[1], g->camera_pos[2]);
@@ -730,24 +746,29 @@ void orc_shade(const OrcGlobals* g, const OrcShadeInputs* in, int flags,
             v3 sun_emission = V3(25.0f * 1.0f, 25.0f * 0.9f, 25.0f * 0.7f);               /* :616 */
             v3 outgoing = V3(0, 0, 0);
 
-            /* :622-651 light shafts with visibility == 1 (optional) */
+            /* :622-651 light shafts; visibility from the sun depth map with ORC_SHADE_SHADOWS, else 1 */
             if (flags & ORC_SHADE_SHAFTS) {
                 const float intensity = 0.001f;
-                float sp4[4] = {p0_world.x + Nn.x * 0.1f, p0_world.y + Nn.y * 0.1f, p0_world.z + Nn.z * 0.1f, 1.0f}; /* :596 */
-                float p0s[4]; mat4_mul_v4(g->sun_space_from_world, sp4, p0s);            /* :597 */
                 float c4[4] = {cam.x, cam.y, cam.z, 1.0f};
                 float rp[4]; mat4_mul_v4(g->sun_space_from_world, c4, rp);               /* :627 */
+                v3 pos = V3(rp[0], rp[1], rp[2]);
                 v3 delta = V3(p0s[0] - rp[0], p0s[1] - rp[1], p0s[2] - rp[2]);            /* :630 */
                 float dist = sqrtf(v3_dot(delta, delta));
                 float travelled = 0.0f;
                 const float step = 1.0f / 16.0f;
+                v3 stepv = V3(step * (delta.x / dist), step * (delta.y / dist), step * (delta.z / dist));   /* :635 */
+                pos = V3(pos.x + stepv.x * noise_1, pos.y + stepv.y * noise_1, pos.z + stepv.z * noise_1);   /* :637 */
                 travelled += step * noise_1;                                             /* :638 */
-                for (;;) {                                                               /* :640-650 */
+                for (int guard = 0; guard < 65536; ++guard) {                            /* :640-650 */
+                    pos = v3_add(pos, stepv);
                     travelled += step;
                     if (travelled > dist) break;
-                    outgoing.x += intensity * 1.0f * sun_emission.x;
-                    outgoing.y += intensity * 1.0f * sun_emission.y;
-                    outgoing.z += intensity * 1.0f * sun_emission.z;
+                    float visibility = 1.0f;
+                    if (flags & ORC_SHADE_SHADOWS)
+                        visibility = orc_shadow_sample(&in->sun_depth_map, pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z);   /* :644-646 */
+                    outgoing.x += intensity * visibility * sun_emission.x;
+                    outgoing.y += intensity * visibility * sun_emission.y;
+                    outgoing.z += intensity * visibility * sun_emission.z;
                 }
             }
 
@@ -903,6 +924,21 @@ void orc_tex2d_sample(const OrcTex2D* t, float u, float v, float out[4]) {
     float t00[4], t10[4], t01[4], t11[4];
     tex2d_texel(t, i0, j0, t00); tex2d_texel(t, i1, j0, t10); tex2d_texel(t, i0, j1, t01); tex2d_texel(t, i1, j1, t11);
     for (int k = 0; k < 4; ++k) out[k] = lerpf(lerpf(t00[k], t10[k], a), lerpf(t01[k], t11[k], a), b);
+}
+
+float orc_shadow_sample(const OrcTex2D* t, float u, float v, float ref) {
+    float fx = u * (float)t->width - 0.5f, fy = v * (float)t->height - 0.5f;
+    fx = floorf(fx * 256.0f + 0.5f) * (1.0f / 256.0f);
+    fy = floorf(fy * 256.0f + 0.5f) * (1.0f / 256.0f);
+    float flx = floorf(fx), fly = floorf(fy);
+    float a = fx - flx, b = fy - fly;
+    int i0 = (int)flx, j0 = (int)fly, i1 = i0 + 1, j1 = j0 + 1;
+    i0 = clampi(i0, 0, t->width - 1); i1 = clampi(i1, 0, t->width - 1);
+    j0 = clampi(j0, 0, t->height - 1); j1 = clampi(j1, 0, t->height - 1);
+    const float* d = (const float*)t->data;
+    float c00 = ref < d[(size_t)j0 * t->width + i0] ? 1.0f : 0.0f, c10 = ref < d[(size_t)j0 * t->width + i1] ? 1.0f : 0.0f;
+    float c01 = ref < d[(size_t)j1 * t->width + i0] ? 1.0f : 0.0f, c11 = ref < d[(size_t)j1 * t->width + i1] ? 1.0f : 0.0f;
+    return lerpf(lerpf(c00, c10, a), lerpf(c01, c11, a), b);
 }
 
 static float mitchell_netravali(float x) {                        /* taa_resolve.glsl:13-26 */

@@ -43,7 +43,8 @@ typedef struct OrcGlobals {
 enum {
     ORC_SHADE_IBL       = 1 << 0, /* ambient = irradiance(N), spec = prefiltered(R, rough*4) (lighting_pass.glsl:690,699) */
     ORC_SHADE_SHAFTS    = 1 << 1, /* light-shaft loop with visibility == 1 (lighting_pass.glsl:622-651) */
-    ORC_SHADE_ANALYTIC  = 1 << 2  /* analytic stand-ins for the env/irradiance/prefiltered/LUT textures */
+    ORC_SHADE_ANALYTIC  = 1 << 2, /* analytic stand-ins for the env/irradiance/prefiltered/LUT textures */
+    ORC_SHADE_SHADOWS   = 1 << 3  /* sun shadow PCF (:594-608) and light-shaft visibility (:646) from sun_depth_map */
 };
 
 void   orc_set_threads(int n);
@@ -144,7 +145,13 @@ typedef struct OrcShadeInputs {
     int            prefiltered_size, prefiltered_levels;
     const uint16_t* lut;         /* [S][S][2] fp16 */
     int            lut_size;
+    /* inputs of the live shader's raster-fed blocks; each is read only under its flag */
+    OrcTex2D       sun_depth_map;   /* R32F (render.cpp:676 D32F 2048^2): ORC_SHADE_SHADOWS, lighting_pass.glsl:594-608 and :646 */
 } OrcShadeInputs;
+
+/* sampler2DShadow with SAMPLER_PERCENTAGE_CLOSER (render.cpp:664-673: linear, clamp, compare Less): each of the four
+ * bilinear taps contributes (ref < texel ? 1 : 0); coordinates snapped to 1/256 texel like orc_tex2d_sample.  Unpinned. */
+float  orc_shadow_sample(const OrcTex2D* depth_map, float u, float v, float ref);
 
 /* bilinear, clamp-to-edge fetch of an RG16F texture (lighting_pass.glsl:681 BRDF_INTEGRATION_MAP) */
 void   orc_lut_sample(const uint16_t* lut, int size, float u, float v, float out[2]);

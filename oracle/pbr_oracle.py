@@ -54,10 +54,11 @@ class OrcShadeInputs(C.Structure):
         ("irradiance", C.c_void_p), ("irradiance_size", C.c_int),
         ("prefiltered", C.c_void_p), ("prefiltered_size", C.c_int), ("prefiltered_levels", C.c_int),
         ("lut", C.c_void_p), ("lut_size", C.c_int),
+        ("sun_depth_map", OrcTex2D),
     ]
 
 
-SHADE_IBL, SHADE_SHAFTS, SHADE_ANALYTIC = 1, 2, 4
+SHADE_IBL, SHADE_SHAFTS, SHADE_ANALYTIC, SHADE_SHADOWS = 1, 2, 4, 8
 
 
 def build(force=False):
@@ -108,6 +109,8 @@ def lib():
     L.orc_final_post_process.argtypes = [C.POINTER(OrcTex2D), C.c_int, C.c_int, C.c_int, C.c_int, f32p]
     L.orc_bloom_downsample.argtypes = [C.POINTER(OrcTex2D), C.c_int, C.c_int, C.c_int, f32p]
     L.orc_bloom_upsample.argtypes = [C.POINTER(OrcTex2D), C.c_int, C.c_int, C.c_int, f32p]
+    L.orc_shadow_sample.argtypes = [C.POINTER(OrcTex2D), C.c_float, C.c_float, C.c_float]
+    L.orc_shadow_sample.restype = C.c_float
     L.orc_unorm8.argtypes = [C.c_float]
     L.orc_unorm8.restype = C.c_uint8
     L.orc_shade.argtypes = [C.POINTER(OrcGlobals), C.POINTER(OrcShadeInputs), C.c_int,
@@ -259,7 +262,7 @@ def make_globals(mats: dict, sun_direction, camera_pos, frame_idx_mod_59=0.0, li
 
 
 def shade(g, base, normal, orm, emissive, depth, flags=0, irradiance_cube=None, prefiltered_pyr=None,
-          prefiltered_size=0, lut_half=None, region=None):
+          prefiltered_size=0, lut_half=None, region=None, sun_depth_map=None):
     H, W = depth.shape
     keep = [np.ascontiguousarray(a, dtype=np.uint8) for a in (base, normal, orm, emissive)]
     depth = np.ascontiguousarray(depth, dtype=np.float32)
@@ -280,6 +283,8 @@ def shade(g, base, normal, orm, emissive, depth, flags=0, irradiance_cube=None, 
         lut_half = np.ascontiguousarray(lut_half, dtype=np.uint16)
         si.lut = _ptr(lut_half)
         si.lut_size = lut_half.shape[0]
+    if sun_depth_map is not None:
+        si.sun_depth_map, keep_sun = _tex2d(np.asarray(sun_depth_map, np.float32), TEX_R32F)
     out = np.zeros((H, W, 4), dtype=np.float32)
     x0, x1, y0, y1 = region if region is not None else (0, W, 0, H)
     lib().orc_shade(C.byref(g), C.byref(si), int(flags), x0, x1, y0, y1, out)

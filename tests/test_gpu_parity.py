@@ -261,3 +261,59 @@ def test_shade_random_bytes_all_decodes(gpu):
     assert rel_err(got[..., :3], want[..., :3], floor=1e-2) < REL, rel_err(got[..., :3], want[..., :3], floor=1e-2)
     gpu.GPU_DestroyGraph(g); gpu.PBR_DestroyLightingPass(lp); gpu.PBR_DestroyGBuffer(C.byref(gb))
     gpu.PBR_DestroyIBLMaps(C.byref(maps)); gpu.GPU_DestroyTexture(env_tex)
+
+
+@pytest.mark.parametrize("mode", ["live_shafts_shadows", "ibl_shadows"])
+def test_shade_sun_shadows_vs_oracle(gpu, mode):
+    """lighting_pass.glsl:594-608 (4-tap PCF sun shadow) and :646 (light-shaft visibility) with a synthetic sun depth map bound to
+    SUN_DEPTH_MAP: K5 vs the oracle, which reproduces the shader text bit for bit on this block (tests/test_oracle_cpu.py)."""
+    import pbrhip, pbr_oracle as O
+    from pbrhip import synth
+    W, H = 256, 144
+    gbd, env_tex, maps, gb, lp0, glob = _shade_setup(gpu, W, H, pbrhip.Format_RGBA32F)
+    # centre the synthetic map on the scene's depth as the sun sees it, so that lit and shadowed pixels both occur
+    M = lambda a: np.array(a, np.float64).reshape(4, 4).T
+    ys, xs = np.nonzero(gbd["depth"] < 1)
+    ndc = np.stack([(xs + 0.5) / W * 2 - 1, (ys + 0.5) / H * 2 - 1, gbd["depth"][ys, xs], np.ones(len(xs))], -1)
+    pw = ndc @ M(glob.world_space_from_clip).T
+    ps = np.concatenate([pw[:, :3] / pw[:, 3:], np.ones((len(xs), 1))], 1) @ M(glob.sun_space_from_world).T
+    v, u = np.mgrid[0:512, 0:512] / 512.0                           # the whole scene covers ~0.14 of the map: use fine ripples
+    sun = (np.median(ps[:, 2]) + 0.08 * np.sin(2 * np.pi * 40 * u) * np.cos(2 * np.pi * 36 * v)).astype(np.float32)
+    sun_tex = pbrhip.make_texture(pbrhip.Format_D32F_Or_X8D24UN, 512, 512, pbrhip.TextureFlag_RenderTarget)
+    pbrhip.upload_mip(sun_tex, 0, sun)
+    lp = gpu.PBR_MakeLightingPassEx(C.byref(gb), C.byref(maps), W, H, sun_tex)
+    gflags, oflags = {"live_shafts_shadows": (pbrhip.Shade_LightShafts | pbrhip.Shade_SunShadows, O.SHADE_SHAFTS | O.SHADE_SHADOWS),
+                      "ibl_shadows": (pbrhip.Shade_IBL | pbrhip.Shade_SunShadows, O.SHADE_IBL | O.SHADE_SHADOWS)}[mode]
+    g = gpu.GPU_MakeGraph()
+    res = {}
+    for name, fl in (("shadowed", gflags), ("lit", gflags & ~pbrhip.Shade_SunShadows)):
+        gpu.GPUX_SetShadeFlags(gpu.PBR_LightingPipeline(lp), fl)
+        gpu.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
+        gpu.GPU_GraphSubmit(g); gpu.GPU_GraphWait(g)
+        res[name] = pbrhip.read_mip(gb.lighting_result, 0)
+    irr = pbrhip.read_mip(maps.irradiance_map, 0)
+    n = maps.tex_specular_env_map.contents.mip_level_count
+    pyr = np.concatenate([pbrhip.read_mip(maps.tex_specular_env_map, m).ravel() for m in range(n)])
+    og = O.OrcGlobals.from_buffer_copy(bytes(glob))
+    want = O.shade(og, gbd["base"], gbd["normal"], gbd["orm"], gbd["emissive"], gbd["depth"], flags=oflags, irradiance_cube=irr,
+                   prefiltered_pyr=pyr, prefiltered_size=maps.tex_specular_env_map.contents.width,
+                   lut_half=pbrhip.read_mip(maps.brdf_lut, 0).view(np.uint16), sun_depth_map=sun)
+    got = res["shadowed"]
+    assert rmse_rel(got, want) < REL
+    assert rel_err(got[..., :3], want[..., :3], floor=1e-2) < REL, rel_err(got[..., :3], want[..., :3], floor=1e-2)
+    darker = (got[..., :3].sum(-1) < res["lit"][..., :3].sum(-1) * 0.999) & (gbd["depth"] < 1)
+    assert darker.mean() > 0.02, darker.mean()                       # the map really shadows part of the spheres
+    # the flag without a usable map is refused at record time
+    msgs = []
+    CB = C.CFUNCTYPE(None, C.c_char_p, C.c_void_p)
+    cb = CB(lambda m, u: msgs.append(m.decode()))
+    gpu.GPUX_SetErrorHandler(C.cast(cb, C.c_void_p), None)
+    try:
+        gpu.GPUX_SetShadeFlags(gpu.PBR_LightingPipeline(lp0), pbrhip.Shade_SunShadows)
+        gpu.PBR_RecordLightingPass(lp0, g, C.byref(glob), 0, 0)                          # lp0 has the 1x1 stand-in: fine (D32F)
+        assert not msgs
+        gpu.GPU_GraphSubmit(g); gpu.GPU_GraphWait(g)
+    finally:
+        gpu.GPUX_SetErrorHandler(None, None)
+    gpu.GPU_DestroyGraph(g); gpu.PBR_DestroyLightingPass(lp); gpu.PBR_DestroyLightingPass(lp0); gpu.PBR_DestroyGBuffer(C.byref(gb))
+    gpu.PBR_DestroyIBLMaps(C.byref(maps)); gpu.GPU_DestroyTexture(env_tex); gpu.GPU_DestroyTexture(sun_tex)

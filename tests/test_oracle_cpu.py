@@ -116,13 +116,13 @@ def test_lighting_kats_and_tile(O, golden_dir, meta):
     variants = (("live_noshaft", O.SHADE_ANALYTIC), ("live_shaft", O.SHADE_ANALYTIC | O.SHADE_SHAFTS),
                 ("ibl", O.SHADE_ANALYTIC | O.SHADE_IBL))
 
-    def run(pixels, flags):
+    def run(pixels, flags, sun=None):
         base = np.zeros((H, W, 4), np.uint8); nrm = base.copy(); orm = base.copy(); emi = base.copy()
         dep = np.ones((H, W), np.float32)
         res = np.zeros((len(pixels), 4), np.float32)
         for k, (x, y, b, n, o, e, d) in enumerate(pixels):
             base[y, x] = b; nrm[y, x] = n; orm[y, x] = o; emi[y, x] = e; dep[y, x] = d
-            res[k] = O.shade(g, base, nrm, orm, emi, dep, flags=flags, region=(x, x + 1, y, y + 1))[y, x]
+            res[k] = O.shade(g, base, nrm, orm, emi, dep, flags=flags, region=(x, x + 1, y, y + 1), sun_depth_map=sun)[y, x]
         return res
 
     kat = meta["lighting_kats"]
@@ -137,6 +137,16 @@ def test_lighting_kats_and_tile(O, golden_dir, meta):
     for name, flags in variants:
         want = np.load(os.path.join(golden_dir, f"oracle_a_lighting_tile_{name}.npy"))[::9]
         assert rel(run(pixels, flags)[:, :3], want[:, :3], floor=1e-3) <= 1e-6, name
+    # the sun-shadow block + shaft visibility (lighting_pass.glsl:594-608, 646) against a synthetic sun depth map
+    from pbrhip import synth
+    sun = synth.synth_sun_depth(256, 0x5EED00E0)
+    want = np.load(os.path.join(golden_dir, "oracle_a_lighting_tile_live_shadow.npy"))[::9]
+    got = run(pixels, O.SHADE_ANALYTIC | O.SHADE_SHAFTS | O.SHADE_SHADOWS, sun)
+    assert np.array_equal(got[:, :3].view(np.uint32), want[:, :3].view(np.uint32))
+    lit = np.load(os.path.join(golden_dir, "oracle_a_lighting_tile_live_shaft.npy"))[::9]
+    assert (want[:, :3].sum(1) < lit[:, :3].sum(1) - 1e-6).sum() > 40          # a good share of the pixels is in shadow
+    t = O._tex2d(sun, O.TEX_R32F)[0]
+    assert O.lib().orc_shadow_sample(t, 0.3, 0.3, -1.0) == 1.0 and O.lib().orc_shadow_sample(t, 0.3, 0.3, 2.0) == 0.0
 
 
 def test_cube_neighbor_geometry(O):

@@ -946,6 +946,11 @@ static void record_shade(GPU_Graph* g, uint32_t row0, uint32_t row1, bool explic
     GPU_REQUIRE_V(gl && gl->buf && gl->buf->base.size >= 552, "%s: \"GLOBALS\" must be a buffer of at least 552 bytes (render.h:122-136)", fn);
     Slot* pre = named_slot(s, "PREFILTERED_ENV_MAP");
     GPU_REQUIRE_V(pre && pre->tex && is_f4_cube(pre->tex), "%s: \"PREFILTERED_ENV_MAP\" must be a square RGBA32F cubemap", fn);
+    if (dp.pipeline->shade_flags & GPUX_Shade_SunShadows) {
+        Slot* sun = named_slot(s, "SUN_DEPTH_MAP");
+        GPU_REQUIRE_V(sun && sun->tex && sun->tex->base.format == GPU_Format_D32F_Or_X8D24UN && sun->tex->base.layer_count == 1 && sun->tex->base.depth == 1,
+                      "%s: \"SUN_DEPTH_MAP\" must be a 2D D32F texture (render.cpp:676)", fn);
+    }
     if (dp.pipeline->shade_flags & GPUX_Shade_IBL) {
         Slot* irr = named_slot(s, "TEX_IRRADIANCE_MAP");
         GPU_REQUIRE_V(irr && irr->tex && is_f4_cube(irr->tex), "%s: \"TEX_IRRADIANCE_MAP\" must be a square RGBA32F cubemap", fn);
@@ -1318,6 +1323,11 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
             a.lut_cells = lut->lut_cells_valid ? lut->lut_cells : nullptr;
         }
         if (op.gpipe->shade_flags & GPUX_Shade_LightShafts) a.flags |= PBRK_SHADE_SHAFTS;
+        if (op.gpipe->shade_flags & GPUX_Shade_SunShadows) {
+            TextureImpl* sun = named_slot(s, "SUN_DEPTH_MAP")->tex;
+            a.flags |= PBRK_SHADE_SHADOWS;
+            a.sun_depth = sun->dev; a.sun_depth_w = (int)sun->base.width; a.sun_depth_h = (int)sun->base.height;
+        }
         a.out = target->dev;
         a.out_format = target->base.format == GPU_Format_RGBA16F ? PBRK_FMT_RGBA16F : PBRK_FMT_RGBA32F;
         BufferImpl* gb = named_slot(s, "GLOBALS")->buf;

@@ -29,7 +29,25 @@ struct ShadeParams {
     float ssw[16];       // sun_space_from_world (light shafts only)
     float sun[3], cam[3], frame_idx_mod_59;
     float rcp_width, rcp_height;   // RN(1/width), RN(1/height), computed on the host
+    const float* sun_depth; int sun_w, sun_h;
 };
+
+// sampler2DShadow + SAMPLER_PERCENTAGE_CLOSER (render.cpp:664-673: linear, clamp, compare Less): each bilinear tap contributes
+// (ref < texel ? 1 : 0); coordinates snapped to 1/256 texel (the 2-D sampler convention of k_post.hip / the oracle).  EXACT.
+__device__ __forceinline__ float shadow_sample(const float* __restrict__ d, int w, int h, float u, float v, float ref) {
+    float fx = u * (float)w - 0.5f, fy = v * (float)h - 0.5f;
+    fx = floorf(fx * 256.0f + 0.5f) * (1.0f / 256.0f);
+    fy = floorf(fy * 256.0f + 0.5f) * (1.0f / 256.0f);
+    float flx = floorf(fx), fly = floorf(fy);
+    float a = fx - flx, b = fy - fly;
+    int i0 = (int)flx, j0 = (int)fly;
+    int i1 = min(max(i0 + 1, 0), w - 1), j1 = min(max(j0 + 1, 0), h - 1);
+    i0 = min(max(i0, 0), w - 1); j0 = min(max(j0, 0), h - 1);
+    float c00 = ref < d[j0 * w + i0] ? 1.0f : 0.0f, c10 = ref < d[j0 * w + i1] ? 1.0f : 0.0f;
+    float c01 = ref < d[j1 * w + i0] ? 1.0f : 0.0f, c11 = ref < d[j1 * w + i1] ? 1.0f : 0.0f;
+    float top = c00 + a * (c10 - c00), bot = c01 + a * (c11 - c01);
+    return top + b * (bot - top);
+}
 
 __device__ __forceinline__ float fract_(float x) { return x - floorf(x); }
 // EXACT b / 255.0f for b in 0..255 in 3 instructions: one Newton correction of b * fl(1/255) is the correctly
@@ -167,7 +185,23 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
         float noise_2 = fract_(ign(fcx + 90.0f, fcy + 20.0f) + noise_offset);
         float noise_3 = fract_(ign(fcx + 522.0f, fcy + 55.0f) + noise_offset);
 
-        const float shadow = 1.0f;                                                     // :594-608 out of scope
+        // :594-608 sun shadow (1 without PBRK_SHADE_SHADOWS); p0_sun_space also feeds the light shafts
+        float shadow = 1.0f;
+        float sp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (p.flags & (PBRK_SHADE_SHADOWS | PBRK_SHADE_SHAFTS))
+            mat_mul(p.ssw, P.x + N.x * 0.1f, P.y + N.y * 0.1f, P.z + N.z * 0.1f, 1.0f, sp);   // :596-597 sun_space_from_world
+        if (p.flags & PBRK_SHADE_SHADOWS) {
+            const float px_size = 1.0f / 2048.0f;                                      // :594 (a constant of the shader, not the map's size)
+            float sx = sp[0] * 0.5f + 0.5f, sy = sp[1] * 0.5f + 0.5f, sz = sp[2];
+            sx = sx + (2.0f * (noise_2 - 0.5f)) * px_size;                             // :600
+            sy = sy + (2.0f * (noise_1 - 0.5f)) * px_size;
+            float acc = 0.0f;
+            acc = acc + shadow_sample(p.sun_depth, p.sun_w, p.sun_h, sx + 0.75f * px_size, sy + 0.25f * px_size, sz);
+            acc = acc + shadow_sample(p.sun_depth, p.sun_w, p.sun_h, sx + -0.25f * px_size, sy + 0.75f * px_size, sz);
+            acc = acc + shadow_sample(p.sun_depth, p.sun_w, p.sun_h, sx + 0.25f * px_size, sy + -0.75f * px_size, sz);
+            acc = acc + shadow_sample(p.sun_depth, p.sun_w, p.sun_h, sx + -0.75f * px_size, sy + -0.25f * px_size, sz);
+            shadow = acc * 0.25f;
+        }
         f3 cam = mk3(p.cam[0], p.cam[1], p.cam[2]);
         f3 V = normalize3(sub3(cam, P));                                               // :612
         float VdotN = fmaxf(dot3(V, N), 0.0f);                                         // :613
@@ -181,22 +215,35 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
         if (sky) {
             outl = pyramid_fetch(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, mk3(-V.x, -V.y, -V.z), 1.0f, level_tab);
         } else {
-            if (p.flags & PBRK_SHADE_SHAFTS) {                                   // :622-651 (visibility == 1)
-                float sp[4], cp4[4];
-                mat_mul(p.ssw, P.x + N.x * 0.1f, P.y + N.y * 0.1f, P.z + N.z * 0.1f, 1.0f, sp);   // :596-597 sun_space_from_world
+            if (p.flags & PBRK_SHADE_SHAFTS) {                                   // :622-651
+                float cp4[4];
                 mat_mul(p.ssw, cam.x, cam.y, cam.z, 1.0f, cp4);                          // :627
                 f3 delta = mk3(sp[0] - cp4[0], sp[1] - cp4[1], sp[2] - cp4[2]);
                 float dist = sqrtf(dot3(delta, delta));
                 const float step = 1.0f / 16.0f;
                 float travelled = 0.0f;
                 travelled += step * noise_1;                                               // :638
-                // bounded: non-sky pixels lie within +-99 world units => dist < 16 in sun space
-                for (int it = 0; it < 4096; ++it) {
-                    travelled += step;
-                    if (travelled > dist) break;
-                    outl.x += 0.001f * 1.0f * sun_emission.x;
-                    outl.y += 0.001f * 1.0f * sun_emission.y;
-                    outl.z += 0.001f * 1.0f * sun_emission.z;
+                if (p.flags & PBRK_SHADE_SHADOWS) {                                      // visibility from the sun depth map (:644-646)
+                    f3 stepv = mk3(step * (delta.x / dist), step * (delta.y / dist), step * (delta.z / dist));   // :635
+                    f3 pos = mk3(cp4[0] + stepv.x * noise_1, cp4[1] + stepv.y * noise_1, cp4[2] + stepv.z * noise_1);   // :637
+                    for (int it = 0; it < 4096; ++it) {                                  // bounded like below
+                        pos = add3(pos, stepv);
+                        travelled += step;
+                        if (travelled > dist) break;
+                        float vis = shadow_sample(p.sun_depth, p.sun_w, p.sun_h, pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z);
+                        outl.x += 0.001f * vis * sun_emission.x;
+                        outl.y += 0.001f * vis * sun_emission.y;
+                        outl.z += 0.001f * vis * sun_emission.z;
+                    }
+                } else {
+                    // bounded: non-sky pixels lie within +-99 world units => dist < 16 in sun space
+                    for (int it = 0; it < 4096; ++it) {
+                        travelled += step;
+                        if (travelled > dist) break;
+                        outl.x += 0.001f * 1.0f * sun_emission.x;
+                        outl.y += 0.001f * 1.0f * sun_emission.y;
+                        outl.z += 0.001f * 1.0f * sun_emission.z;
+                    }
                 }
             }
 
@@ -295,6 +342,9 @@ extern "C" int pbrk_shade(const PbrkShadeArgs* a, void* stream) {
     if (a->flags & PBRK_SHADE_IBL) {
         if (!a->irradiance_bordered || a->irradiance_size < 1 || !a->lut || a->lut_size < 1) return PBRK_E_ARG;
     }
+    if (a->flags & PBRK_SHADE_SHADOWS) {
+        if (!a->sun_depth || a->sun_depth_w < 1 || a->sun_depth_h < 1 || (long long)a->sun_depth_w * a->sun_depth_h > (1ll << 30)) return PBRK_E_ARG;
+    }
     ShadeParams p;
     p.width = a->width; p.height = a->height; p.x0 = a->x0; p.y0 = a->y0; p.w = a->x1 - a->x0; p.h = a->y1 - a->y0;
     p.base = (const uchar4*)a->base_color; p.normal = (const uchar4*)a->normal; p.orm = (const uchar4*)a->orm;
@@ -308,6 +358,7 @@ extern "C" int pbrk_shade(const PbrkShadeArgs* a, void* stream) {
     for (int i = 0; i < 16; ++i) { p.wfc[i] = a->globals[32 + i]; p.ssw[i] = a->globals[96 + i]; }
     for (int i = 0; i < 3; ++i) { p.sun[i] = a->globals[128 + i]; p.cam[i] = a->globals[132 + i]; }
     p.frame_idx_mod_59 = a->globals[135];
+    p.sun_depth = (const float*)a->sun_depth; p.sun_w = a->sun_depth_w; p.sun_h = a->sun_depth_h;
     p.rcp_width = 1.0f / (float)a->width; p.rcp_height = 1.0f / (float)a->height;
     hipLaunchKernelGGL(k_shade, dim3((p.w + 63) / 64, (p.h + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;

@@ -186,6 +186,10 @@ struct PBR_LightingPass {
 };
 
 PBR_LightingPass* PBR_MakeLightingPass(const PBR_GBuffer* gb, const PBR_IBLMaps* maps, uint32_t width, uint32_t height) {
+    return PBR_MakeLightingPassEx(gb, maps, width, height, NULL);
+}
+
+PBR_LightingPass* PBR_MakeLightingPassEx(const PBR_GBuffer* gb, const PBR_IBLMaps* maps, uint32_t width, uint32_t height, GPU_Texture* sun_depth_map) {
     PBR_LightingPass* lp = (PBR_LightingPass*)calloc(1, sizeof *lp);
     /* render.cpp:664-675 */
     GPU_SamplerDesc pcf; memset(&pcf, 0, sizeof pcf);
@@ -250,7 +254,7 @@ PBR_LightingPass* PBR_MakeLightingPass(const PBR_GBuffer* gb, const PBR_IBLMaps*
     GPU_SetTextureBinding(s, lut_b, maps->brdf_lut);
     GPU_SetTextureBinding(s, grid_b, lp->dummy3d);
     GPU_SetTextureBinding(s, prev_b, lp->dummy2d);
-    GPU_SetTextureBinding(s, sun_b, lp->dummy_depth);
+    GPU_SetTextureBinding(s, sun_b, sun_depth_map ? sun_depth_map : lp->dummy_depth);            /* render.cpp:676 sun_depth_rt */
     GPU_SetSamplerBinding(s, s_lc, GPU_SamplerLinearClamp());
     GPU_SetSamplerBinding(s, s_lw, GPU_SamplerLinearWrap());
     GPU_SetSamplerBinding(s, s_nc, GPU_SamplerNearestClamp());

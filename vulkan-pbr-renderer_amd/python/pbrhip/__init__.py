@@ -94,6 +94,7 @@ class PbrkFinalArgs(C.Structure):
                 ("y0", C.c_int), ("y1", C.c_int)]
 
 
+Shade_IBL, Shade_LightShafts, Shade_SunShadows = 1, 2, 4
 PBRK_FMT_RG16F, PBRK_FMT_RG32F, PBRK_FMT_RGBA16F, PBRK_FMT_RGBA32F, PBRK_FMT_R32F, PBRK_FMT_RGBA8UN, PBRK_FMT_BGRA8UN = 1, 2, 3, 4, 5, 6, 7
 
 
@@ -103,7 +104,9 @@ class PbrkShadeArgs(C.Structure):
                 ("depth", C.c_void_p), ("irradiance_bordered", C.c_void_p), ("irradiance_size", C.c_int),
                 ("prefiltered_bordered", C.c_void_p), ("prefiltered_size", C.c_int), ("prefiltered_levels", C.c_int),
                 ("lut", C.c_void_p), ("lut_size", C.c_int), ("irradiance_cells", C.c_void_p), ("prefiltered_cells", C.c_void_p),
-                ("prefiltered_cells_first", C.c_int), ("lut_cells", C.c_void_p), ("out", C.c_void_p), ("out_format", C.c_int), ("flags", C.c_int),
+                ("prefiltered_cells_first", C.c_int), ("lut_cells", C.c_void_p),
+                ("sun_depth", C.c_void_p), ("sun_depth_w", C.c_int), ("sun_depth_h", C.c_int),
+                ("out", C.c_void_p), ("out_format", C.c_int), ("flags", C.c_int),
                 ("globals", C.c_float * 138)]
 
 
@@ -177,6 +180,7 @@ PROTOTYPES = {
                                C.c_float, C.c_float, C.c_float, C.c_float, U32]),
     "PBR_MakeGBuffer": (None, [C.POINTER(PBR_GBuffer), U32, U32, C.c_int]), "PBR_DestroyGBuffer": (None, [C.POINTER(PBR_GBuffer)]),
     "PBR_MakeLightingPass": (VP, [C.POINTER(PBR_GBuffer), C.POINTER(PBR_IBLMaps), U32, U32]), "PBR_DestroyLightingPass": (None, [VP]),
+    "PBR_MakeLightingPassEx": (VP, [C.POINTER(PBR_GBuffer), C.POINTER(PBR_IBLMaps), U32, U32, TexP]),
     "PBR_LightingGlobalsBuffer": (BufP, [VP]), "PBR_LightingPipeline": (VP, [VP]),
     "PBR_RecordLightingPass": (None, [VP, VP, C.POINTER(PBR_Globals), U32, U32]),
     "PBR_MakePostProcess": (VP, [C.POINTER(PBR_GBuffer), U32, U32, C.c_int]), "PBR_DestroyPostProcess": (None, [VP]),

@@ -437,3 +437,16 @@ def synth_post_inputs(seed, W, H):
     patch = (slice(H // 3, H // 2), slice(W // 3, W // 2))
     vel_prev[patch] = (vel_prev[patch].astype(np.float32) + 0.01).astype(np.float16)   # velocity-based rejection (:269-270)
     return lighting, depth, vel, vel_prev, history
+
+
+def synth_sun_depth(size=2048, seed=0x5EED00E0):
+    """Stand-in for the sun depth map the shadow raster pass writes (render.cpp:676, D32F): a smooth height field around
+    the sun-space depth of the scene (0.45) plus a few sharp occluder rectangles, float32 [size][size]."""
+    rng = np.random.default_rng(seed)
+    v, u = np.mgrid[0:size, 0:size].astype(np.float64) / size
+    d = 0.45 + 0.3 * np.sin(7.0 * u + 1.0) * np.cos(5.0 * v) + 0.02 * np.sin(61.0 * u) * np.sin(47.0 * v)
+    for _ in range(6):
+        x0, y0 = rng.random(2) * 0.8
+        w, h = 0.05 + rng.random(2) * 0.15
+        d[(u > x0) & (u < x0 + w) & (v > y0) & (v < y0 + h)] = 0.05 + 0.2 * rng.random()
+    return d.astype(np.float32)
