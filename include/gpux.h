@@ -39,7 +39,9 @@ GPU_API void GPUX_OpDispatchLines(GPU_Graph* graph, uint32_t y0, uint32_t y1, ui
 
 /* ---- shade pass controls ---- */
 enum { GPUX_Shade_IBL = 1 << 0, GPUX_Shade_LightShafts = 1 << 1,
-       GPUX_Shade_SunShadows = 1 << 2 /* SUN_DEPTH_MAP: 4-tap PCF sun shadow + shaft visibility (lighting_pass.glsl:594-608, 646) */ };
+       GPUX_Shade_SunShadows = 1 << 2, /* SUN_DEPTH_MAP: 4-tap PCF sun shadow + shaft visibility (lighting_pass.glsl:594-608, 646) */
+       GPUX_Shade_VoxelGI = 1 << 3     /* LIGHTGRID + PREV_FRAME_RESULT + GBUFFER_DEPTH: the live ambient / specular traces (:273-424, :685, :701);
+                                          with LightShafts | SunShadows | VoxelGI the pass is the reference's complete live shader */ };
 GPU_API void GPUX_SetShadeFlags(GPU_GraphicsPipeline* pipeline, int flags);    /* default GPUX_Shade_IBL */
 /* full-screen draw restricted to rows [row0,row1) (screen-band sharding) */
 GPU_API void GPUX_OpDrawRows(GPU_Graph* graph, uint32_t row0, uint32_t row1);

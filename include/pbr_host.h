@@ -106,6 +106,11 @@ PBR_LightingPass* PBR_MakeLightingPass(const PBR_GBuffer* gb, const PBR_IBLMaps*
 /* the same with the sun depth map of the shadow pass bound to SUN_DEPTH_MAP (render.cpp:676, :863; D32F); NULL = 1x1 stand-in.
  * GPUX_SetShadeFlags(PBR_LightingPipeline(lp), ... | GPUX_Shade_SunShadows) makes the pass read it. */
 PBR_LightingPass* PBR_MakeLightingPassEx(const PBR_GBuffer* gb, const PBR_IBLMaps* maps, uint32_t width, uint32_t height, GPU_Texture* sun_depth_map);
+/* all raster-fed inputs of the live shader (render.cpp:861-863): the swept light grid (PBR_LightgridTexture), the previous frame
+ * as the lighting pass sees it (the reference binds bloom_downscale_rt: PBR_PostBloomDownscale) and the sun depth map; NULLs = stand-ins.
+ * GPUX_Shade_LightShafts | GPUX_Shade_SunShadows | GPUX_Shade_VoxelGI then runs the reference's complete live shader. */
+PBR_LightingPass* PBR_MakeLightingPassLive(const PBR_GBuffer* gb, const PBR_IBLMaps* maps, uint32_t width, uint32_t height,
+                                           GPU_Texture* sun_depth_map, GPU_Texture* lightgrid, GPU_Texture* prev_frame_result);
 void PBR_DestroyLightingPass(PBR_LightingPass* lp);
 GPU_Buffer* PBR_LightingGlobalsBuffer(PBR_LightingPass* lp);           /* persistently mapped (render.cpp:675) */
 GPU_GraphicsPipeline* PBR_LightingPipeline(PBR_LightingPass* lp);

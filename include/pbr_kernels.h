@@ -44,7 +44,8 @@ enum {                      /* output formats understood by the kernels */
 enum {                      /* shade flags (reference lighting_pass.glsl sub-blocks) */
     PBRK_SHADE_IBL = 1 << 0,     /* ambient = irradiance(N); spec = prefiltered(R, rough*4)  (:690, :699) */
     PBRK_SHADE_SHAFTS = 1 << 1,  /* light-shaft loop (:622-651); visibility == 1 unless PBRK_SHADE_SHADOWS */
-    PBRK_SHADE_SHADOWS = 1 << 2  /* sun shadow: 4 PCF taps of the sun depth map (:594-608) + shaft visibility (:646) */
+    PBRK_SHADE_SHADOWS = 1 << 2, /* sun shadow: 4 PCF taps of the sun depth map (:594-608) + shaft visibility (:646) */
+    PBRK_SHADE_GI = 1 << 3       /* the live ambient / specular terms: SampleRadianceWithScreenSpaceTrace (:273-424, :685, :701) */
 };
 
 /* sizes / offsets of the pyramid layouts, in float4 texels */
@@ -135,6 +136,11 @@ typedef struct PbrkShadeArgs {
     const void* lut_cells;              /* uint4 [(S+1)][(S+1)]: {t00,t10,t01,t11} half2, tap origin (-1,-1), clamp-to-edge */
     const void* sun_depth;              /* float [sun_depth_h][sun_depth_w] (SUN_DEPTH_MAP, render.cpp:676); PBRK_SHADE_SHADOWS */
     int sun_depth_w, sun_depth_h;
+    const void* lightgrid;              /* half4 [n][n][n] (LIGHTGRID, render.cpp:678, after the sweeps); PBRK_SHADE_GI */
+    int lightgrid_size;
+    const void* prev_frame[8];          /* PREV_FRAME_RESULT mip chain, half4 per level (the reference binds bloom_downscale_rt, render.cpp:862) */
+    int prev_frame_w, prev_frame_h;     /* level 0 extent; level l is max(1, w >> l) x max(1, h >> l) */
+    int prev_frame_levels;              /* 1..8 */
     void* out;                          /* half4 or float4 [H][W] */
     int out_format;                     /* PBRK_FMT_RGBA16F / PBRK_FMT_RGBA32F */
     int flags;                          /* PBRK_SHADE_* */

@@ -37,6 +37,7 @@ TEX_IDS = {
     "GBUFFER_EMISSIVE": 13, "GBUFFER_DEPTH": 14, "PREV_FRAME_RESULT": 15, "TEX_IRRADIANCE_MAP": 20,
     "PREFILTERED_ENV_MAP": 21, "BRDF_INTEGRATION_MAP": 22, "SUN_DEPTH_MAP": 23, "LIGHTGRID": 24,
     "LIGHTING_RESULT": 30, "GBUFFER_VELOCITY": 31, "GBUFFER_VELOCITY_PREV": 32, "TEX0": 33,
+    "SAMPLER_NEAREST_CLAMP": 101,
 }
 
 FLOAT_LIT = re.compile(r"(?<![\w.])(\d+\.\d*(?:[eE][+-]?\d+)?|\.\d+(?:[eE][+-]?\d+)?|\d+[eE][+-]?\d+)(?![\w.])")
@@ -100,6 +101,7 @@ vec4 (*shim_cube_lookup)(int, vec3, float);
 vec4 (*shim_tex2d_lookup)(int, vec2, float);
 ivec2 (*shim_tex2d_size)(int);
 float (*shim_shadow_lookup)(int, vec3);
+vec4 (*shim_tex3d_lookup)(int, vec3);
 static std::vector<float> load_f32(const char* path) {
     FILE* f = fopen(path, "rb"); if (!f) { perror(path); exit(2); }
     fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
@@ -218,6 +220,72 @@ int main(int argc, char** argv) {
         out[i * 4 + 0] = S::out_color.x; out[i * 4 + 1] = S::out_color.y; out[i * 4 + 2] = S::out_color.z; out[i * 4 + 3] = S::out_color.w;
     }
     save_f32(argv[6], out.data(), out.size());
+    return 0;
+}
+"""
+
+DRIVER_LIGHTING_FULL = DRIVER_COMMON + r"""
+namespace S {
+#include "SHADER_INC"
+}
+// The complete live lighting shader on a full frame: G-buffer planes, sun depth map (PCF), light grid (3-D), previous-frame
+// pyramid.  argv: W H globals.bin gbuffer.bin grid.bin n prev.bin pw ph plevels sun.bin sw sh out.bin
+static int g_W, g_H, g_x, g_y;
+static std::vector<unsigned char> g_planes; static std::vector<float> g_depth, g_sun; static std::vector<uint16_t> g_grid, g_prev;
+static int g_n; static OrcTex2D g_prev_lv[16]; static int g_prev_n; static OrcTex2D g_sun_tex;
+static vec4 u8v(const unsigned char* p) { return vec4(p[0] / 255.0f, p[1] / 255.0f, p[2] / 255.0f, p[3] / 255.0f); }
+static vec4 tex2d_cb(int id, vec2 uv, float lod) {
+    size_t pi = (size_t)g_y * g_W + g_x, plane = (size_t)g_W * g_H * 4;
+    switch (id) {
+    case 10: return u8v(&g_planes[0 * plane + pi * 4]);
+    case 11: return u8v(&g_planes[1 * plane + pi * 4]);
+    case 12: return u8v(&g_planes[2 * plane + pi * 4]);
+    case 13: return u8v(&g_planes[3 * plane + pi * 4]);
+    case 14: return vec4(g_depth[pi], 0.f, 0.f, 1.f);                                              // point fetch at the pixel centre
+    case 1014: return vec4(orc_tex2d_nearest_r32f(g_depth.data(), g_W, g_H, uv.x, uv.y), 0.f, 0.f, 1.f);   // SAMPLER_NEAREST_CLAMP
+    case 15: { float o[4]; orc_tex2d_sample_lod(g_prev_lv, g_prev_n, uv.x, uv.y, lod, o); return vec4(o[0], o[1], o[2], o[3]); }
+    case 22: return vec4(0.9f - 0.5f * uv.y, 0.02f + 0.1f * (1.0f - uv.x), 0.f, 1.f);               // analytic LUT stand-in
+    default: return vec4(0.f);
+    }
+}
+static vec4 cube_cb(int, vec3 d, float) { float dd[3] = {d.x, d.y, d.z}, o[4]; orc_env_analytic(dd, o); return vec4(o[0], o[1], o[2], o[3]); }
+static vec4 grid_cb(int, vec3 p) { float pp[3] = {p.x, p.y, p.z}, o[4]; orc_tex3d_sample(g_grid.data(), g_n, pp, o); return vec4(o[0], o[1], o[2], o[3]); }
+static float shadow_cb(int, vec3 p) { return orc_shadow_sample(&g_sun_tex, p.x, p.y, p.z); }
+template <class T> static std::vector<T> load_raw(const char* path) {
+    FILE* f = fopen(path, "rb"); if (!f) { perror(path); exit(2); }
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<T> v(n / sizeof(T)); if (fread(v.data(), 1, n, f) != (size_t)n) exit(3); fclose(f); return v;
+}
+int main(int argc, char** argv) {
+    if (argc < 15) return 1;
+    g_W = atoi(argv[1]); g_H = atoi(argv[2]);
+    std::vector<float> gl = load_f32(argv[3]);
+    memcpy(&S::GLOBALS.data, gl.data(), 552);
+    std::vector<unsigned char> gbuf = load_raw<unsigned char>(argv[4]);
+    size_t plane = (size_t)g_W * g_H * 4;
+    g_planes.assign(gbuf.begin(), gbuf.begin() + 4 * plane);
+    g_depth.resize((size_t)g_W * g_H); memcpy(g_depth.data(), gbuf.data() + 4 * plane, g_depth.size() * 4);
+    g_grid = load_raw<uint16_t>(argv[5]); g_n = atoi(argv[6]);
+    g_prev = load_raw<uint16_t>(argv[7]);
+    int pw = atoi(argv[8]), ph = atoi(argv[9]); g_prev_n = atoi(argv[10]);
+    size_t off = 0;
+    for (int l = 0; l < g_prev_n; l++) {
+        int w = pw >> l > 0 ? pw >> l : 1, h = ph >> l > 0 ? ph >> l : 1;
+        g_prev_lv[l].data = g_prev.data() + off; g_prev_lv[l].format = ORC_TEX_RGBA16F; g_prev_lv[l].width = w; g_prev_lv[l].height = h;
+        off += (size_t)w * h * 4;
+    }
+    g_sun = load_f32(argv[11]);
+    g_sun_tex.data = g_sun.data(); g_sun_tex.format = ORC_TEX_R32F; g_sun_tex.width = atoi(argv[12]); g_sun_tex.height = atoi(argv[13]);
+    shim_cube_lookup = cube_cb; shim_tex2d_lookup = tex2d_cb; shim_tex3d_lookup = grid_cb; shim_shadow_lookup = shadow_cb;
+    std::vector<float> out((size_t)g_W * g_H * 4);
+    for (g_y = 0; g_y < g_H; g_y++) for (g_x = 0; g_x < g_W; g_x++) {
+        S::fs_uv = vec2((g_x + 0.5f) / (float)g_W, (g_y + 0.5f) / (float)g_H);
+        gl_FragCoord = vec4(g_x + 0.5f, g_y + 0.5f, g_depth[(size_t)g_y * g_W + g_x], 1.0f);
+        S::shader_main();
+        float* o = &out[((size_t)g_y * g_W + g_x) * 4];
+        o[0] = S::out_color.x; o[1] = S::out_color.y; o[2] = S::out_color.z; o[3] = S::out_color.w;
+    }
+    save_f32(argv[14], out.data(), out.size());
     return 0;
 }
 """
@@ -386,6 +454,56 @@ def gen_shadow(meta):
                                     "note": "variant live_shaft + SUN_DEPTH_MAP sampled with the oracle's PCF sampler"}
 
 
+def gen_gi(meta):
+    """The complete live lighting shader (shafts + sun shadows + voxel GI with its screen-space trace) on a 96x54 frame of the
+    spheres scene; sin/cos/acos are the deterministic fp32 polynomials of the oracle (SHIM_DET_TRIG), samplers the oracle's."""
+    import ctypes as C
+    import pbr_oracle as O
+    from pbrhip import synth
+    W, H = 96, 54
+    gbd, grid, levels, sun = synth.synth_gi_scene(W, H)
+    subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
+    R = C.CDLL(os.path.join(HERE, "_ref", "libref_thirdparty.so"))
+    gbuf = np.zeros(140, np.float32)
+    R.ref_fill_globals((C.c_float * 3)(*synth.GI_SCENE_CAMERA), (C.c_float * 4)(0, 0, 0, 1), 1, C.c_float(75), C.c_float(W / H),
+                       C.c_float(.02), C.c_float(1e4), C.c_float(56.5), C.c_float(97), 3, gbuf.ctypes.data_as(C.c_void_p))
+    gbuf[136] = 1.0 / synth.GI_SCENE_EXTENT                     # lightgrid_scale of the test scene
+    np.save(os.path.join(GOLDEN, "ref_globals_gi_scene.npy"), gbuf[:138].copy())
+    gp = os.path.join(SCRATCH, "gi_globals.bin"); gbuf.tofile(gp)
+    gb = os.path.join(SCRATCH, "gi_gbuffer.bin")
+    with open(gb, "wb") as f:
+        for k in ("base", "normal", "orm", "emissive"):
+            f.write(np.ascontiguousarray(gbd[k]).tobytes())
+        f.write(np.ascontiguousarray(gbd["depth"], np.float32).tobytes())
+    grp = os.path.join(SCRATCH, "gi_grid.bin"); np.ascontiguousarray(grid).tofile(grp)
+    pp = os.path.join(SCRATCH, "gi_prev.bin")
+    with open(pp, "wb") as f:
+        for lv in levels:
+            f.write(np.ascontiguousarray(lv).tobytes())
+    sp = os.path.join(SCRATCH, "gi_sun.bin"); sun.tofile(sp)
+    CXX.extend(["-DSHIM_DET_TRIG", "-DSHIM_SAMPLER_IDS"])
+    try:
+        exe = build("lighting_full", "lighting_pass.glsl", DRIVER_LIGHTING_FULL, lighting_variant="live_shaft")
+    finally:
+        del CXX[-2:]
+    outp = os.path.join(SCRATCH, "gi_out.bin")
+    subprocess.check_call([exe, str(W), str(H), gp, gb, grp, str(grid.shape[0]), pp, str(levels[0].shape[1]), str(levels[0].shape[0]),
+                           str(len(levels)), sp, str(sun.shape[1]), str(sun.shape[0]), outp])
+    out = np.fromfile(outp, dtype=np.float32).reshape(H, W, 4)
+    g = O.OrcGlobals.from_buffer_copy(gbuf.tobytes()[:552])
+    O.gi_exit_counts()
+    mine = O.shade(g, gbd["base"], gbd["normal"], gbd["orm"], gbd["emissive"], gbd["depth"],
+                   flags=O.SHADE_ANALYTIC | O.SHADE_SHAFTS | O.SHADE_SHADOWS | O.SHADE_GI, sun_depth_map=sun, lightgrid=grid, prev_frame_levels=levels)
+    print("GI exits (fallback, screen hit, no open point, voxel march):", O.gi_exit_counts())
+    bad = (mine.view(np.uint32) != out.view(np.uint32)).any(-1)
+    print("full live shader: oracle-B mismatching pixels", int(bad.sum()), "of", W * H, "; surface pixels", int((gbd["depth"] < 1).sum()))
+    np.save(os.path.join(GOLDEN, "oracle_a_lighting_full_gi.npy"), out)
+    meta["lighting_full_gi"] = {"file": "oracle_a_lighting_full_gi.npy", "width": W, "height": H, "globals": "ref_globals_gi_scene.npy",
+                                "scene": "pbrhip.synth.synth_gi_scene(96, 54)", "camera": "pos pbrhip.synth.GI_SCENE_CAMERA, default orientation, fov 75, frame 3",
+                                "note": "lighting_pass.glsl with shafts, sun shadows and SampleRadianceWithScreenSpaceTrace live; "
+                                        "sin/cos/acos = oracle's deterministic polynomials; LUT / sky = analytic stand-ins"}
+
+
 def gen_sweep(meta):
     import pbr_oracle as O
     exe = build("sweep", "lightgrid_sweep.glsl", DRIVER_SWEEP)
@@ -504,7 +622,7 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--only":       # regenerate one group, keep the rest of the metadata
         with open(os.path.join(GOLDEN, "oracle_a_meta.json")) as f:
             meta = json.load(f)
-        {"sweep": gen_sweep, "post": gen_post, "bloom": gen_bloom, "shadow": gen_shadow}[sys.argv[2]](meta)
+        {"sweep": gen_sweep, "post": gen_post, "bloom": gen_bloom, "shadow": gen_shadow, "gi": gen_gi}[sys.argv[2]](meta)
         with open(os.path.join(GOLDEN, "oracle_a_meta.json"), "w") as f:
             json.dump(meta, f, indent=1)
         return
@@ -616,6 +734,7 @@ def main():
     meta["lighting_tile"] = {"inputs": "oracle_a_lighting_tile_inputs.npy", "seed": 0x5EED00AC, "count": n}
 
     gen_shadow(meta)
+    gen_gi(meta)
     gen_sweep(meta)
     gen_post(meta)
     gen_bloom(meta)

@@ -98,10 +98,20 @@ inline bool operator==(vec3 a, vec3 b) { return a.x == b.x && a.y == b.y && a.z 
 inline bool operator!=(vec3 a, vec3 b) { return !(a == b); }
 
 // ---- scalar builtins (fp32 only) ----------------------------------------------------------
+#if defined(SHIM_DET_TRIG)   // voxel-GI variant: the fixed fp32 polynomials shared with the oracle and the kernel (pbr_oracle.h, N4)
+extern "C" float orc_sinf_det(float), orc_cosf_det(float), orc_acosf_det(float);
+inline float sin(float x) { return orc_sinf_det(x); }
+inline float cos(float x) { return orc_cosf_det(x); }
+#else
 inline float sin(float x) { return sinf(x); }
 inline float cos(float x) { return cosf(x); }
+#endif
 inline float tan(float x) { return tanf(x); }
+#if defined(SHIM_DET_TRIG)
+inline float acos(float x) { return orc_acosf_det(x); }
+#else
 inline float acos(float x) { return acosf(x); }
+#endif
 inline float exp(float x) { return expf(x); }
 inline float sqrt(float x) { return sqrtf(x); }
 inline float floor(float x) { return floorf(x); }
@@ -188,7 +198,11 @@ struct H_2d { int id; };
 struct H_3d { int id; };
 struct H_shadow { int id; };
 inline H_cube samplerCube(textureCube t, sampler) { return H_cube{t.id}; }
+#if defined(SHIM_SAMPLER_IDS)   // sampler id 101 = SAMPLER_NEAREST_CLAMP: reported to the callback as texture id + 1000
+inline H_2d sampler2D(texture2D t, sampler s) { return H_2d{t.id + (s.id == 101 ? 1000 : 0)}; }
+#else
 inline H_2d sampler2D(texture2D t, sampler) { return H_2d{t.id}; }
+#endif
 inline H_3d sampler3D(texture3D t, sampler) { return H_3d{t.id}; }
 inline H_shadow sampler2DShadow(texture2D t, samplerShadow) { return H_shadow{t.id}; }
 
@@ -200,7 +214,8 @@ inline vec4 textureLod(H_2d h, vec2 uv, float lod) { return shim_tex2d_lookup(h.
 inline vec4 texture(H_2d h, vec2 uv) { return shim_tex2d_lookup(h.id, uv, 0.0f); }
 extern ivec2 (*shim_tex2d_size)(int id);
 inline ivec2 textureSize(H_2d h, int) { return shim_tex2d_size(h.id); }
-inline vec4 texture(H_3d, vec3) { return vec4(0.0f); }         // LIGHTGRID == 0 (out of scope)
+extern vec4 (*shim_tex3d_lookup)(int id, vec3 p);               // NULL: LIGHTGRID == 0
+inline vec4 texture(H_3d h, vec3 p) { return shim_tex3d_lookup ? shim_tex3d_lookup(h.id, p) : vec4(0.0f); }
 extern float (*shim_shadow_lookup)(int id, vec3 uv_ref);       // NULL: shadow map == fully lit
 inline float texture(H_shadow h, vec3 p) { return shim_shadow_lookup ? shim_shadow_lookup(h.id, p) : 1.0f; }
 

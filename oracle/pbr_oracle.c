@@ -688,6 +688,171 @@ static void prefiltered_sample(const OrcShadeInputs* in, int flags, v3 d, float 
     cube_sample(in->prefiltered, in->prefiltered_size, in->prefiltered_levels, d, lod, out);
 }
 
+/* ---- N4: deterministic trig, samplers, voxel / screen-space trace ---- */
+static void sincos_det(float x, float* sn, float* cs) {
+    /* k = nearest multiple of pi/2, r = x - k*pi/2 (two-constant Cody-Waite), then the [-pi/4, pi/4] polynomials */
+    float kf = floorf(x * 0.63661977236758134f + 0.5f);
+    float r = fmaf(-kf, 1.5707962512969971f, x);
+    r = fmaf(-kf, 7.5497894158615964e-08f, r);
+    float z = r * r;
+    float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+    float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+    int k = (int)kf & 3;
+    *sn = (k == 0) ? ps : (k == 1) ? pc : (k == 2) ? -ps : -pc;
+    *cs = (k == 0) ? pc : (k == 1) ? -ps : (k == 2) ? -pc : ps;
+}
+float orc_sinf_det(float x) { float s, c; sincos_det(x, &s, &c); return s; }
+float orc_cosf_det(float x) { float s, c; sincos_det(x, &s, &c); return c; }
+static float asin_poly_det(float x) {       /* |x| <= 0.5 */
+    float z = x * x;
+    float p = fmaf(fmaf(fmaf(fmaf(4.2163199048e-2f, z, 2.4181311049e-2f), z, 4.5470025998e-2f), z, 7.4953002686e-2f), z, 1.6666752422e-1f);
+    return fmaf(p * z, x, x);
+}
+float orc_acosf_det(float x) {              /* x in [0, 1] */
+    if (x > 0.5f) return 2.0f * asin_poly_det(sqrtf(0.5f * (1.0f - x)));
+    return 1.5707963267948966f - asin_poly_det(x);
+}
+
+static void snap_split(float coord01, int extent, int* i0, int* i1, float* a) {
+    float f = coord01 * (float)extent - 0.5f;
+    f = floorf(f * 256.0f + 0.5f) * (1.0f / 256.0f);
+    float fl = floorf(f);
+    *a = f - fl;
+    int i = (int)fminf(fmaxf(fl, -1.0f), (float)extent);       /* clamp before converting: rays may have marched to 1e30 */
+    *i0 = clampi(i, 0, extent - 1); *i1 = clampi(i + 1, 0, extent - 1);
+}
+void orc_tex3d_sample(const uint16_t* grid, int n, const float p[3], float out[4]) {
+    int i0, i1, j0, j1, k0, k1; float a, b, c;
+    snap_split(p[0], n, &i0, &i1, &a); snap_split(p[1], n, &j0, &j1, &b); snap_split(p[2], n, &k0, &k1, &c);
+    const int ii[2] = {i0, i1}, jj[2] = {j0, j1}, kk[2] = {k0, k1};
+    for (int ch = 0; ch < 4; ++ch) {
+        float t[2][2][2];
+        for (int z = 0; z < 2; ++z) for (int y = 0; y < 2; ++y) for (int x = 0; x < 2; ++x)
+            t[z][y][x] = orc_f16_to_f32(grid[(((size_t)kk[z] * n + jj[y]) * n + ii[x]) * 4 + ch]);
+        float z0 = lerpf(lerpf(t[0][0][0], t[0][0][1], a), lerpf(t[0][1][0], t[0][1][1], a), b);
+        float z1 = lerpf(lerpf(t[1][0][0], t[1][0][1], a), lerpf(t[1][1][0], t[1][1][1], a), b);
+        out[ch] = lerpf(z0, z1, c);
+    }
+}
+float orc_tex2d_nearest_r32f(const float* d, int w, int h, float u, float v) {
+    int i = clampi((int)fminf(fmaxf(floorf(u * (float)w), 0.0f), (float)w), 0, w - 1), j = clampi((int)fminf(fmaxf(floorf(v * (float)h), 0.0f), (float)h), 0, h - 1);
+    return d[(size_t)j * w + i];
+}
+void orc_tex2d_sample_lod(const OrcTex2D* levels, int nlevels, float u, float v, float lod, float out[4]) {
+    lod = fminf(fmaxf(lod, 0.0f), (float)(nlevels - 1));
+    float fl = floorf(lod);
+    int l0 = (int)fl;
+    float w = lod - fl;
+    orc_tex2d_sample(&levels[l0], u, v, out);
+    if (w > 0.0f) {
+        float o1[4]; orc_tex2d_sample(&levels[l0 + 1 < nlevels ? l0 + 1 : nlevels - 1], u, v, o1);
+        for (int k = 0; k < 4; ++k) out[k] = lerpf(out[k], o1[k], w);
+    }
+}
+
+static void grid_at(const OrcShadeInputs* in, v3 ro, float out[4]) {          /* texture(LIGHTGRID, ro*0.5 + 0.5) */
+    float p[3] = {ro.x * 0.5f + 0.5f, ro.y * 0.5f + 0.5f, ro.z * 0.5f + 0.5f};
+    orc_tex3d_sample(in->lightgrid, in->lightgrid_size, p, out);
+}
+static v3 luminance_normalise(const float sum[4]) {                          /* :267-269, :314-316, :420-422 */
+    float luminance = 0.299f * sum[0] + 0.587f * sum[1] + 0.114f * sum[2];
+    float k = sqrtf(luminance) / fmaxf(luminance, 0.0001f);
+    return V3(sum[0] * k, sum[1] * k, sum[2] * k);
+}
+
+/* exit statistics of the trace (test infrastructure: lets a test assert that a fixture reaches every exit) */
+static uint64_t g_gi_exits[4];      /* 0 off-screen fallback, 1 screen-space hit, 2 no open point, 3 voxel march */
+void orc_gi_exit_counts(uint64_t out[4], int reset) {
+    for (int k = 0; k < 4; ++k) { out[k] = g_gi_exits[k]; if (reset) g_gi_exits[k] = 0; }
+}
+#define GI_EXIT(k) do { _Pragma("omp atomic") g_gi_exits[k]++; } while (0)
+
+/* lighting_pass.glsl:273-424 SampleRadianceWithScreenSpaceTrace */
+static v3 sample_radiance_ss(const OrcGlobals* g, const OrcShadeInputs* in, v3 V, const float p0_vs[4], v3 ray_origin, v3 ray_direction,
+                             int num_steps, float step_scale, float noise_01, float foggyness, float ss_intensity) {
+    const float voxel_scale = 2.0f / 128.0f;                                             /* :274 */
+    const float ls = g->lightgrid_scale;
+    v3 rd = v3_scale(ray_direction, voxel_scale);
+    v3 ro = v3_scale(ray_origin, ls);
+    float sum[4] = {0.0f, 0.0f, 0.0f, 0.0001f};
+    for (int i = 0; i < 4; ++i) {                                                        /* :281-288 skip the initial blockage */
+        ro = v3_add(ro, rd);
+        float rad[4]; grid_at(in, ro, rad);
+        if (rad[3] < 0.3f) { sum[0] += rad[0]; sum[1] += rad[1]; sum[2] += rad[2]; sum[3] += 1.0f; break; }
+    }
+    float opw[4] = {ro.x / ls, ro.y / ls, ro.z / ls, 1.0f}, open_vs[4];
+    mat4_mul_v4(g->view_space_from_world, opw, open_vs);                                 /* :290 */
+    float d4[4] = {open_vs[0] - p0_vs[0], open_vs[1] - p0_vs[1], open_vs[2] - p0_vs[2], open_vs[3] - p0_vs[3]};   /* :298 */
+    float step_length = fmaxf(p0_vs[2], 1.0f) * (1.0f + noise_01) / 100.0f;              /* :300 */
+    float lxy = sqrtf(d4[0] * d4[0] + d4[1] * d4[1]);
+    v3 ssray_dir = V3(d4[0] / lxy, d4[1] / lxy, d4[2] / lxy);                            /* :301 */
+    v3 ssray_step = v3_scale(ssray_dir, step_length);
+    v3 pos = V3(p0_vs[0], p0_vs[1], p0_vs[2]);                                           /* :304 */
+    float dist_to_travel = sqrtf(d4[0] * d4[0] + d4[1] * d4[1] + d4[2] * d4[2]);         /* :308 */
+    float dist_travelled = 0.0f;
+    for (int guard = 0; guard < 512; ++guard) {                                          /* :315 for (;;): steps grow >= 1.2x, see header */
+        pos = v3_add(pos, ssray_step);
+        dist_travelled += step_length;
+        float pv[4] = {pos.x, pos.y, pos.z, 1.0f}, ndc[4];
+        mat4_mul_v4(g->clip_space_from_view, pv, ndc);                                   /* :319-320 */
+        float nw = ndc[3];
+        ndc[0] = ndc[0] / nw; ndc[1] = ndc[1] / nw; ndc[2] = ndc[2] / nw; ndc[3] = ndc[3] / nw;
+        float cx = fminf(fmaxf(ndc[0], -1.0f), 1.0f), cy = fminf(fmaxf(ndc[1], -1.0f), 1.0f);
+        if (cx != ndc[0] || cy != ndc[1]) {                                              /* :322-330 left the screen: fallback */
+            v3 fp = V3(ray_origin.x * ls + 2.5f * V.x * voxel_scale, ray_origin.y * ls + 2.5f * V.y * voxel_scale, ray_origin.z * ls + 2.5f * V.z * voxel_scale);
+            float s4[4]; grid_at(in, fp, s4);
+            GI_EXIT(0);
+            return luminance_normalise(s4);
+        }
+        ssray_step = v3_scale(ssray_step, 1.2f); step_length *= 1.2f;                    /* :332-333 */
+        float depth_ndc = orc_tex2d_nearest_r32f(in->depth, in->width, in->height, ndc[0] * 0.5f + 0.5f, ndc[1] * 0.5f + 0.5f);   /* :335 */
+        float sn[4] = {ndc[0], ndc[1], depth_ndc, 1.0f}, surf[4];
+        mat4_mul_v4(g->view_space_from_clip, sn, surf);                                  /* :338-339 */
+        float sw = surf[3];
+        surf[0] = surf[0] / sw; surf[1] = surf[1] / sw; surf[2] = surf[2] / sw; surf[3] = surf[3] / sw;
+        float ls_surf = sqrtf(surf[0] * surf[0] + surf[1] * surf[1] + surf[2] * surf[2]);
+        float ls_pos = sqrtf(pos.x * pos.x + pos.y * pos.y + pos.z * pos.z);
+        if (ls_surf < ls_pos) {                                                          /* :343 the ray is behind the visible surface */
+            float ts[4], te[4], pe[4] = {pos.x, pos.y, pos.z, 1.0f};
+            mat4_mul_v4(g->world_space_from_view, surf, ts);                             /* :348-349 */
+            mat4_mul_v4(g->world_space_from_view, pe, te);
+            for (int k = 0; k < 4; ++k) { ts[k] = ts[k] * ls * 0.5f + 0.5f; te[k] = te[k] * ls * 0.5f + 0.5f; }
+            float noise_offset = noise_01 * 0.2f;                                        /* :351 */
+            float alpha = 0.0f;
+            const float tt[3] = {noise_offset + 0.2f, noise_offset + 0.4f, noise_offset + 0.6f};
+            for (int k = 0; k < 3; ++k) {                                                /* :352-355 */
+                float mp[3] = {mixf(ts[0], te[0], tt[k]), mixf(ts[1], te[1], tt[k]), mixf(ts[2], te[2], tt[k])}, r4[4];
+                orc_tex3d_sample(in->lightgrid, in->lightgrid_size, mp, r4);
+                alpha = (k == 0) ? r4[3] : alpha + r4[3];
+            }
+            if (alpha < 1.5f) {                                                          /* :357-361 thin: keep marching, faster */
+                float f = 2.0f + noise_01;
+                ssray_step = v3_scale(ssray_step, f); step_length *= f;
+                continue;
+            }
+            float rad[4];                                                                /* :372-382 solid: last frame's radiance on screen */
+            orc_tex2d_sample_lod(in->prev_frame, in->prev_frame_levels, ndc[0] * 0.5f + 0.5f, ndc[1] * 0.5f + 0.5f, fminf(step_length * 5.0f, 5.0f), rad);
+            GI_EXIT(1);
+            return V3(rad[0] * ss_intensity, rad[1] * ss_intensity, rad[2] * ss_intensity);
+        }
+        if (dist_travelled > dist_to_travel) break;                                      /* :393 */
+    }
+    if (sum[3] < 0.5f) { GI_EXIT(2); return V3(0, 0, 0); }                               /* :400-403 */
+    rd = v3_scale(rd, step_scale);                                                       /* :407-408 */
+    ro = V3(ro.x + rd.x * noise_01, ro.y + rd.y * noise_01, ro.z + rd.z * noise_01);
+    for (int i = 0; i < num_steps; ++i) {                                                /* :411-419 continue until hitting a voxel */
+        ro = V3(ro.x + 0.5f * rd.x, ro.y + 0.5f * rd.y, ro.z + 0.5f * rd.z);
+        float rad[4]; grid_at(in, ro, rad);
+        if (rad[3] > 0.3f) break;
+        sum[0] = sum[0] * foggyness + rad[0]; sum[1] = sum[1] * foggyness + rad[1]; sum[2] = sum[2] * foggyness + rad[2];
+        sum[3] = sum[3] * foggyness + 1.0f;
+    }
+    float sw = sum[3];
+    sum[0] = sum[0] / sw; sum[1] = sum[1] / sw; sum[2] = sum[2] / sw; sum[3] = sum[3] / sw;   /* :421 */
+    GI_EXIT(3);
+    return luminance_normalise(sum);
+}
+
 void orc_shade(const OrcGlobals* g, const OrcShadeInputs* in, int flags,
                int x0, int x1, int y0, int y1, float* out_rgba) {
     const int W = in->width, H = in->height;
@@ -807,6 +972,26 @@ void orc_shade(const OrcGlobals* g, const OrcShadeInputs* in, int flags,
                 float ir[4]; irradiance_sample(in, flags, Nn, ir);
                 ambient = V3(ir[0], ir[1], ir[2]);
             }
+            /* the sky test of :708 decides early here: sky pixels overwrite everything, so their traces are not evaluated */
+            const int sky_px = (fminf(fmaxf(p0_world.x, -99.0f), 99.0f) != p0_world.x) ||
+                               (fminf(fmaxf(p0_world.y, -99.0f), 99.0f) != p0_world.y) ||
+                               (fminf(fmaxf(p0_world.z, -99.0f), 99.0f) != p0_world.z);
+            float p0_view[4] = {0, 0, 0, 1};
+            if ((flags & ORC_SHADE_GI) && !sky_px) {
+                float pv[4]; mat4_mul_v4(g->view_space_from_clip, p0_ndc, pv);              /* :446-447 */
+                p0_view[0] = pv[0] / pv[3]; p0_view[1] = pv[1] / pv[3]; p0_view[2] = pv[2] / pv[3]; p0_view[3] = pv[3] / pv[3];
+                /* :546-577 random direction in the hemisphere around N (cosine-distributed pitch) */
+                v3 some_vector = v3_normalize(V3(0.7128864983f, 0.8217892113f, 0.948912748f));
+                v3 tangent = v3_normalize(v3_cross(some_vector, Nn));
+                v3 bitangent = v3_cross(Nn, tangent);
+                float pitch = orc_acosf_det(sqrtf(1.0f - noise_1));
+                float yaw = (2.0f * ORC_PI) * noise_3;
+                float sp = orc_sinf_det(pitch), cp = orc_cosf_det(pitch), cyw = orc_cosf_det(yaw), syw = orc_sinf_det(yaw);
+                float lx = sp * cyw, ly = sp * syw, lz = cp;
+                v3 bent = V3((tangent.x * lx + bitangent.x * ly) + Nn.x * lz, (tangent.y * lx + bitangent.y * ly) + Nn.y * lz,
+                             (tangent.z * lx + bitangent.z * ly) + Nn.z * lz);
+                ambient = sample_radiance_ss(g, in, V, p0_view, p0_world, bent, 12, 1.0f, noise_3, 0.5f, 0.75f);   /* :685 */
+            }
             outgoing.x += kD.x * ambient.x * base.x;
             outgoing.y += kD.y * ambient.y * base.y;
             outgoing.z += kD.z * ambient.z * base.z;
@@ -827,6 +1012,8 @@ void orc_shade(const OrcGlobals* g, const OrcShadeInputs* in, int flags,
                 float pc[4]; prefiltered_sample(in, flags, R, roughness * 4.0f, pc);
                 spec = V3(pc[0], pc[1], pc[2]);
             }
+            if ((flags & ORC_SHADE_GI) && !sky_px)
+                spec = sample_radiance_ss(g, in, V, p0_view, p0_world, R, 16, 2.0f, noise_3, roughness, 0.9f);   /* :701 */
             outgoing.x += spec.x * (F0.x * sb[0] + sb[1]);
             outgoing.y += spec.y * (F0.y * sb[0] + sb[1]);
             outgoing.z += spec.z * (F0.z * sb[0] + sb[1]);
@@ -918,7 +1105,7 @@ void orc_tex2d_sample(const OrcTex2D* t, float u, float v, float out[4]) {
     fy = floorf(fy * 256.0f + 0.5f) * (1.0f / 256.0f);
     float flx = floorf(fx), fly = floorf(fy);
     float a = fx - flx, b = fy - fly;
-    int i0 = (int)flx, j0 = (int)fly, i1 = i0 + 1, j1 = j0 + 1;
+    int i0 = (int)fminf(fmaxf(flx, -1.0f), (float)t->width), j0 = (int)fminf(fmaxf(fly, -1.0f), (float)t->height), i1 = i0 + 1, j1 = j0 + 1;
     i0 = clampi(i0, 0, t->width - 1); i1 = clampi(i1, 0, t->width - 1);
     j0 = clampi(j0, 0, t->height - 1); j1 = clampi(j1, 0, t->height - 1);
     float t00[4], t10[4], t01[4], t11[4];
@@ -932,7 +1119,7 @@ float orc_shadow_sample(const OrcTex2D* t, float u, float v, float ref) {
     fy = floorf(fy * 256.0f + 0.5f) * (1.0f / 256.0f);
     float flx = floorf(fx), fly = floorf(fy);
     float a = fx - flx, b = fy - fly;
-    int i0 = (int)flx, j0 = (int)fly, i1 = i0 + 1, j1 = j0 + 1;
+    int i0 = (int)fminf(fmaxf(flx, -1.0f), (float)t->width), j0 = (int)fminf(fmaxf(fly, -1.0f), (float)t->height), i1 = i0 + 1, j1 = j0 + 1;
     i0 = clampi(i0, 0, t->width - 1); i1 = clampi(i1, 0, t->width - 1);
     j0 = clampi(j0, 0, t->height - 1); j1 = clampi(j1, 0, t->height - 1);
     const float* d = (const float*)t->data;

@@ -44,7 +44,8 @@ enum {
     ORC_SHADE_IBL       = 1 << 0, /* ambient = irradiance(N), spec = prefiltered(R, rough*4) (lighting_pass.glsl:690,699) */
     ORC_SHADE_SHAFTS    = 1 << 1, /* light-shaft loop with visibility == 1 (lighting_pass.glsl:622-651) */
     ORC_SHADE_ANALYTIC  = 1 << 2, /* analytic stand-ins for the env/irradiance/prefiltered/LUT textures */
-    ORC_SHADE_SHADOWS   = 1 << 3  /* sun shadow PCF (:594-608) and light-shaft visibility (:646) from sun_depth_map */
+    ORC_SHADE_SHADOWS   = 1 << 3, /* sun shadow PCF (:594-608) and light-shaft visibility (:646) from sun_depth_map */
+    ORC_SHADE_GI        = 1 << 4  /* the live ambient / specular terms: SampleRadianceWithScreenSpaceTrace (:273-424, :685, :701) */
 };
 
 void   orc_set_threads(int n);
@@ -147,7 +148,28 @@ typedef struct OrcShadeInputs {
     int            lut_size;
     /* inputs of the live shader's raster-fed blocks; each is read only under its flag */
     OrcTex2D       sun_depth_map;   /* R32F (render.cpp:676 D32F 2048^2): ORC_SHADE_SHADOWS, lighting_pass.glsl:594-608 and :646 */
+    const uint16_t* lightgrid;      /* RGBA16F [n][n][n][4] (render.cpp:678, after the sweeps): ORC_SHADE_GI */
+    int            lightgrid_size;
+    const OrcTex2D* prev_frame;     /* PREV_FRAME_RESULT: RGBA16F mip chain (the reference binds bloom_downscale_rt, render.cpp:862) */
+    int            prev_frame_levels;
 } OrcShadeInputs;
+
+/* ---- N4: voxel-GI sampling, lighting_pass.glsl:273-424 + :480-562 (bent normal), :685, :701 ----
+ * sin / cos / acos of the per-pixel noise (bent normal, :566-577) decide where rays go and therefore which side of the
+ * alpha > 0.3 / depth thresholds they land on; libm's last-bit differences would flip those branches, so this block is
+ * defined on the fixed fp32 polynomials below (Cephes-style; |err| < 2e-7), shared by oracle, shim (Oracle-A) and kernel. */
+float  orc_sinf_det(float x);       /* x in [0, 2 pi] */
+float  orc_cosf_det(float x);
+float  orc_acosf_det(float x);      /* x in [0, 1] */
+/* texture(sampler3D(LIGHTGRID, SAMPLER_LINEAR_CLAMP), p): trilinear, clamp, coordinates snapped to 1/256 texel; x, y, z order */
+void   orc_tex3d_sample(const uint16_t* grid, int n, const float p[3], float out[4]);
+/* texture(sampler2D(GBUFFER_DEPTH, SAMPLER_NEAREST_CLAMP), uv).r */
+float  orc_tex2d_nearest_r32f(const float* d, int w, int h, float u, float v);
+/* textureLod(sampler2D(PREV_FRAME_RESULT, SAMPLER_LINEAR_CLAMP), uv, lod): bilinear per level, linear between levels, lod clamped */
+void   orc_tex2d_sample_lod(const OrcTex2D* levels, int nlevels, float u, float v, float lod, float out[4]);
+/* how often the trace left through each exit since the last reset: 0 off-screen fallback (:322-330), 1 screen-space hit (:372-382),
+ * 2 no open point (:400-403), 3 voxel march (:411-422) */
+void   orc_gi_exit_counts(uint64_t out[4], int reset);
 
 /* sampler2DShadow with SAMPLER_PERCENTAGE_CLOSER (render.cpp:664-673: linear, clamp, compare Less): each of the four
  * bilinear taps contributes (ref < texel ? 1 : 0); coordinates snapped to 1/256 texel like orc_tex2d_sample.  Unpinned. */

@@ -55,10 +55,12 @@ class OrcShadeInputs(C.Structure):
         ("prefiltered", C.c_void_p), ("prefiltered_size", C.c_int), ("prefiltered_levels", C.c_int),
         ("lut", C.c_void_p), ("lut_size", C.c_int),
         ("sun_depth_map", OrcTex2D),
+        ("lightgrid", C.c_void_p), ("lightgrid_size", C.c_int),
+        ("prev_frame", C.POINTER(OrcTex2D)), ("prev_frame_levels", C.c_int),
     ]
 
 
-SHADE_IBL, SHADE_SHAFTS, SHADE_ANALYTIC, SHADE_SHADOWS = 1, 2, 4, 8
+SHADE_IBL, SHADE_SHAFTS, SHADE_ANALYTIC, SHADE_SHADOWS, SHADE_GI = 1, 2, 4, 8, 16
 
 
 def build(force=False):
@@ -109,6 +111,9 @@ def lib():
     L.orc_final_post_process.argtypes = [C.POINTER(OrcTex2D), C.c_int, C.c_int, C.c_int, C.c_int, f32p]
     L.orc_bloom_downsample.argtypes = [C.POINTER(OrcTex2D), C.c_int, C.c_int, C.c_int, f32p]
     L.orc_bloom_upsample.argtypes = [C.POINTER(OrcTex2D), C.c_int, C.c_int, C.c_int, f32p]
+    L.orc_gi_exit_counts.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    L.orc_sinf_det.argtypes = L.orc_cosf_det.argtypes = L.orc_acosf_det.argtypes = [C.c_float]
+    L.orc_sinf_det.restype = L.orc_cosf_det.restype = L.orc_acosf_det.restype = C.c_float
     L.orc_shadow_sample.argtypes = [C.POINTER(OrcTex2D), C.c_float, C.c_float, C.c_float]
     L.orc_shadow_sample.restype = C.c_float
     L.orc_unorm8.argtypes = [C.c_float]
@@ -262,7 +267,7 @@ def make_globals(mats: dict, sun_direction, camera_pos, frame_idx_mod_59=0.0, li
 
 
 def shade(g, base, normal, orm, emissive, depth, flags=0, irradiance_cube=None, prefiltered_pyr=None,
-          prefiltered_size=0, lut_half=None, region=None, sun_depth_map=None):
+          prefiltered_size=0, lut_half=None, region=None, sun_depth_map=None, lightgrid=None, prev_frame_levels=None):
     H, W = depth.shape
     keep = [np.ascontiguousarray(a, dtype=np.uint8) for a in (base, normal, orm, emissive)]
     depth = np.ascontiguousarray(depth, dtype=np.float32)
@@ -285,6 +290,16 @@ def shade(g, base, normal, orm, emissive, depth, flags=0, irradiance_cube=None, 
         si.lut_size = lut_half.shape[0]
     if sun_depth_map is not None:
         si.sun_depth_map, keep_sun = _tex2d(np.asarray(sun_depth_map, np.float32), TEX_R32F)
+    if lightgrid is not None:
+        grid = np.asarray(lightgrid)
+        grid = np.ascontiguousarray(grid.view(np.uint16) if grid.dtype == np.float16 else grid, dtype=np.uint16)
+        si.lightgrid = grid.ctypes.data_as(C.c_void_p)
+        si.lightgrid_size = grid.shape[0]
+    if prev_frame_levels is not None:
+        pairs = [_tex2d(lv, TEX_RGBA16F) for lv in prev_frame_levels]
+        arr = (OrcTex2D * len(pairs))(*[p[0] for p in pairs])
+        si.prev_frame = C.cast(arr, C.POINTER(OrcTex2D))
+        si.prev_frame_levels = len(pairs)
     out = np.zeros((H, W, 4), dtype=np.float32)
     x0, x1, y0, y1 = region if region is not None else (0, W, 0, H)
     lib().orc_shade(C.byref(g), C.byref(si), int(flags), x0, x1, y0, y1, out)
@@ -391,3 +406,9 @@ def bloom_chain(taa_rgba16f, passes=6):
         blended = frag[..., :3] + up[dst_level][..., :3].astype(np.float32)
         up[dst_level] = np.concatenate([blended, frag[..., 3:]], axis=-1).astype(np.float16)
     return down, up
+
+
+def gi_exit_counts(reset=True):
+    out = (C.c_uint64 * 4)()
+    lib().orc_gi_exit_counts(out, int(reset))
+    return [int(v) for v in out]

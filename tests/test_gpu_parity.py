@@ -317,3 +317,66 @@ def test_shade_sun_shadows_vs_oracle(gpu, mode):
         gpu.GPUX_SetErrorHandler(None, None)
     gpu.GPU_DestroyGraph(g); gpu.PBR_DestroyLightingPass(lp); gpu.PBR_DestroyLightingPass(lp0); gpu.PBR_DestroyGBuffer(C.byref(gb))
     gpu.PBR_DestroyIBLMaps(C.byref(maps)); gpu.GPU_DestroyTexture(env_tex); gpu.GPU_DestroyTexture(sun_tex)
+
+
+@pytest.mark.parametrize("size", [(96, 54), (256, 144)])
+def test_shade_complete_live_shader_vs_oracle(gpu, size):
+    """the reference's complete live lighting shader (light shafts + sun shadows + voxel-GI ambient / specular with
+    the screen-space trace) in K5, against the oracle that reproduces the shader text bit for bit (tests/test_oracle_cpu.py).
+    Rays take data-dependent exits; every pixel must still agree to 1e-4."""
+    import pbrhip, pbr_oracle as O
+    from pbrhip import synth
+    W, H = size
+    L = gpu
+    gbd, grid, levels, sun = synth.synth_gi_scene(W, H)
+    env = synth.synth_env(64, seed=0x5EED00AA)
+    env_tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, 64, 64, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+    maps = pbrhip.PBR_IBLMaps()
+    L.PBR_MakeIBLMaps(C.byref(maps), 16, 64, 32)
+    L.PBR_GenIrradianceMap(env_tex, maps.irradiance_map); L.PBR_GenPrefilteredEnvMap(env_tex, maps.tex_specular_env_map, 1); L.PBR_GenBRDFIntegrationMap(maps.brdf_lut)
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), W, H, pbrhip.Format_RGBA32F)
+    for name, key in (("base_color", "base"), ("normal", "normal"), ("orm", "orm"), ("emissive", "emissive"), ("depth", "depth")):
+        pbrhip.upload_mip(getattr(gb, name), 0, gbd[key])
+    n = grid.shape[0]
+    grid_tex = pbrhip.make_texture(pbrhip.Format_RGBA16F, n, n, pbrhip.TextureFlag_StorageImage, depth=n)
+    pbrhip.upload_mip(grid_tex, 0, grid)
+    prev_tex = pbrhip.make_texture(pbrhip.Format_RGBA16F, levels[0].shape[1], levels[0].shape[0], pbrhip.TextureFlag_RenderTarget | pbrhip.TextureFlag_HasMipmaps)
+    nlev = min(prev_tex.contents.mip_level_count, len(levels))
+    for m in range(nlev):
+        pbrhip.upload_mip(prev_tex, m, levels[m])
+    sun_tex = pbrhip.make_texture(pbrhip.Format_D32F_Or_X8D24UN, sun.shape[1], sun.shape[0], pbrhip.TextureFlag_RenderTarget)
+    pbrhip.upload_mip(sun_tex, 0, sun)
+    lp = L.PBR_MakeLightingPassLive(C.byref(gb), C.byref(maps), W, H, sun_tex, grid_tex, prev_tex)
+    glob = pbrhip.fill_globals(synth.GI_SCENE_CAMERA, aspect=W / H, frame_idx=3)
+    glob.lightgrid_scale = 1.0 / synth.GI_SCENE_EXTENT
+    irr = pbrhip.read_mip(maps.irradiance_map, 0)
+    nm = maps.tex_specular_env_map.contents.mip_level_count
+    pyr = np.concatenate([pbrhip.read_mip(maps.tex_specular_env_map, m).ravel() for m in range(nm)])
+    lut = pbrhip.read_mip(maps.brdf_lut, 0).view(np.uint16)
+    og = O.OrcGlobals.from_buffer_copy(bytes(glob))
+    g = L.GPU_MakeGraph()
+    for gflags, oflags in ((pbrhip.Shade_LightShafts | pbrhip.Shade_SunShadows | pbrhip.Shade_VoxelGI, O.SHADE_SHAFTS | O.SHADE_SHADOWS | O.SHADE_GI),
+                           (pbrhip.Shade_IBL | pbrhip.Shade_VoxelGI, O.SHADE_IBL | O.SHADE_GI)):
+        L.GPUX_SetShadeFlags(L.PBR_LightingPipeline(lp), gflags)
+        L.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
+        L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+        got = pbrhip.read_mip(gb.lighting_result, 0)
+        O.gi_exit_counts()
+        want = O.shade(og, gbd["base"], gbd["normal"], gbd["orm"], gbd["emissive"], gbd["depth"], flags=oflags, irradiance_cube=irr, prefiltered_pyr=pyr,
+                       prefiltered_size=maps.tex_specular_env_map.contents.width, lut_half=lut, sun_depth_map=sun, lightgrid=grid, prev_frame_levels=levels[:nlev])
+        exits = O.gi_exit_counts()
+        assert min(exits) > 0, exits
+        err = np.abs(got[..., :3].astype(np.float64) - want[..., :3]) / np.maximum(np.abs(want[..., :3]), 1e-2)
+        bad = (err.max(-1) >= REL)
+        assert not bad.any(), (int(bad.sum()), float(err.max()), np.argwhere(bad)[:5].tolist())
+    # row bands == full frame (the traces read other pixels' depth, never other pixels' results: no halo of outputs needed)
+    full = got.copy()
+    L.GPU_OpClearColorF(g, gb.lighting_result, 0, 0.0, 0.0, 0.0, 0.0)
+    for r0, r1 in ((0, H // 3), (H // 3, H // 2), (H // 2, H)):
+        L.PBR_RecordLightingPass(lp, g, C.byref(glob), r0, r1)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    assert np.array_equal(pbrhip.read_mip(gb.lighting_result, 0).view(np.uint32), full.view(np.uint32))
+    L.GPU_DestroyGraph(g); L.PBR_DestroyLightingPass(lp); L.PBR_DestroyGBuffer(C.byref(gb)); L.PBR_DestroyIBLMaps(C.byref(maps))
+    for t in (env_tex, grid_tex, prev_tex, sun_tex):
+        L.GPU_DestroyTexture(t)

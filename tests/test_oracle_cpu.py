@@ -242,3 +242,34 @@ def test_f16_conversion(O):
         assert L.orc_f32_to_f16(float(v)) == int(np.float32(v).astype(np.float16).view(np.uint16)), v
     for h in (0, 1, 0x3FF, 0x400, 0x3C00, 0x7BFF, 0x8001, 0xFC00):
         assert np.float32(L.orc_f16_to_f32(h)) == np.uint16(h).view(np.float16).astype(np.float32)
+
+
+def test_full_live_lighting_with_voxel_gi(O, golden_dir, meta):
+    """lighting_pass.glsl with light shafts, sun shadows and SampleRadianceWithScreenSpaceTrace live, executed as
+    shader text on the CPU (oracle/gen_oracle_a.py --only gi), against the oracle: every pixel bit for bit, every exit of
+    the trace exercised."""
+    from pbrhip import synth
+    m = meta["lighting_full_gi"]
+    W, H = m["width"], m["height"]
+    want = np.load(os.path.join(golden_dir, m["file"]))
+    g = O.OrcGlobals.from_buffer_copy(np.load(os.path.join(golden_dir, m["globals"])).tobytes()[:552])
+    assert abs(g.lightgrid_scale - 1.0 / synth.GI_SCENE_EXTENT) < 1e-9
+    gbd, grid, levels, sun = synth.synth_gi_scene(W, H)
+    O.gi_exit_counts()
+    got = O.shade(g, gbd["base"], gbd["normal"], gbd["orm"], gbd["emissive"], gbd["depth"],
+                  flags=O.SHADE_ANALYTIC | O.SHADE_SHAFTS | O.SHADE_SHADOWS | O.SHADE_GI, sun_depth_map=sun, lightgrid=grid, prev_frame_levels=levels)
+    exits = O.gi_exit_counts()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert min(exits) > 100 and sum(exits) == 2 * int((gbd["depth"] < 1).sum()), exits      # two traces per surface pixel
+    # the GI terms matter: without them the frame is different on most surface pixels
+    plain = O.shade(g, gbd["base"], gbd["normal"], gbd["orm"], gbd["emissive"], gbd["depth"],
+                    flags=O.SHADE_ANALYTIC | O.SHADE_SHAFTS | O.SHADE_SHADOWS, sun_depth_map=sun)
+    surf = gbd["depth"] < 1
+    assert (np.abs(got - plain)[surf].max(-1) > 1e-3).mean() > 0.8
+    # deterministic trig: accurate to ~1e-7 on the ranges the shader uses
+    L = O.lib()
+    xs = np.linspace(0, 2 * np.pi, 4001).astype(np.float32)
+    assert max(abs(L.orc_sinf_det(float(x)) - np.sin(np.float64(x))) for x in xs) < 2e-7
+    assert max(abs(L.orc_cosf_det(float(x)) - np.cos(np.float64(x))) for x in xs) < 2e-7
+    xa = np.linspace(0, 1, 2001).astype(np.float32)
+    assert max(abs(L.orc_acosf_det(float(x)) - np.arccos(np.float64(x))) for x in xa) < 3e-7

@@ -951,6 +951,19 @@ static void record_shade(GPU_Graph* g, uint32_t row0, uint32_t row1, bool explic
         GPU_REQUIRE_V(sun && sun->tex && sun->tex->base.format == GPU_Format_D32F_Or_X8D24UN && sun->tex->base.layer_count == 1 && sun->tex->base.depth == 1,
                       "%s: \"SUN_DEPTH_MAP\" must be a 2D D32F texture (render.cpp:676)", fn);
     }
+    if (dp.pipeline->shade_flags & GPUX_Shade_VoxelGI) {
+        Slot* grid = named_slot(s, "LIGHTGRID");
+        GPU_REQUIRE_V(grid && grid->tex && grid->tex->base.format == GPU_Format_RGBA16F && grid->tex->base.layer_count == 1 &&
+                      grid->tex->base.width == grid->tex->base.height && grid->tex->base.width == grid->tex->base.depth && grid->tex->base.width <= 1024,
+                      "%s: \"LIGHTGRID\" must be a cubic RGBA16F 3-D texture (render.cpp:678)", fn);
+        Slot* prev = named_slot(s, "PREV_FRAME_RESULT");
+        GPU_REQUIRE_V(prev && prev->tex && prev->tex->base.format == GPU_Format_RGBA16F && prev->tex->base.layer_count == 1 && prev->tex->base.depth == 1,
+                      "%s: \"PREV_FRAME_RESULT\" must be a 2D RGBA16F texture (render.cpp:862 binds bloom_downscale_rt)", fn);
+        GPU_REQUIRE_V(prev->tex != target, "%s: PREV_FRAME_RESULT aliases the colour target", fn);
+        Slot* lut = named_slot(s, "BRDF_INTEGRATION_MAP");
+        GPU_REQUIRE_V(lut && lut->tex && lut->tex->base.format == GPU_Format_RG16F && lut->tex->base.width == lut->tex->base.height,
+                      "%s: \"BRDF_INTEGRATION_MAP\" must be a square RG16F texture", fn);
+    }
     if (dp.pipeline->shade_flags & GPUX_Shade_IBL) {
         Slot* irr = named_slot(s, "TEX_IRRADIANCE_MAP");
         GPU_REQUIRE_V(irr && irr->tex && is_f4_cube(irr->tex), "%s: \"TEX_IRRADIANCE_MAP\" must be a square RGBA32F cubemap", fn);
@@ -1321,6 +1334,19 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
                 if (lut->lut_cells && pbrk_lut_cells_build(lut->dev, a.lut_size, lut->lut_cells, g->stream) == PBRK_OK) lut->lut_cells_valid = true;
             }
             a.lut_cells = lut->lut_cells_valid ? lut->lut_cells : nullptr;
+        }
+        if (op.gpipe->shade_flags & GPUX_Shade_VoxelGI) {
+            a.flags |= PBRK_SHADE_GI;
+            TextureImpl* grid = named_slot(s, "LIGHTGRID")->tex;
+            a.lightgrid = grid->dev; a.lightgrid_size = (int)grid->base.width;
+            TextureImpl* prev = named_slot(s, "PREV_FRAME_RESULT")->tex;
+            a.prev_frame_levels = (int)(prev->base.mip_level_count < 8 ? prev->base.mip_level_count : 8);
+            a.prev_frame_w = (int)prev->base.width; a.prev_frame_h = (int)prev->base.height;
+            for (int l = 0; l < a.prev_frame_levels; ++l) a.prev_frame[l] = (char*)prev->dev + prev->mip_offset[l];
+            if (!(op.gpipe->shade_flags & GPUX_Shade_IBL)) {                   // the LUT fetch of :681 feeds the GI specular term too
+                TextureImpl* lut = named_slot(s, "BRDF_INTEGRATION_MAP")->tex;
+                a.lut = lut->dev; a.lut_size = (int)lut->base.width;
+            }
         }
         if (op.gpipe->shade_flags & GPUX_Shade_LightShafts) a.flags |= PBRK_SHADE_SHAFTS;
         if (op.gpipe->shade_flags & GPUX_Shade_SunShadows) {

@@ -39,7 +39,7 @@ __device__ __forceinline__ void split_axis(float coord01, int extent, int& i0, i
     f = floorf(f * 256.0f + 0.5f) * (1.0f / 256.0f);
     float fl = floorf(f);
     a = f - fl;
-    int i = (int)fl;
+    int i = (int)fminf(fmaxf(fl, -1.0f), (float)extent);       // clamp before the conversion: no saturation / overflow for wild coordinates
     i0 = clampi(i, 0, extent - 1); i1 = clampi(i + 1, 0, extent - 1);
 }
 

@@ -30,6 +30,11 @@ struct ShadeParams {
     float sun[3], cam[3], frame_idx_mod_59;
     float rcp_width, rcp_height;   // RN(1/width), RN(1/height), computed on the host
     const float* sun_depth; int sun_w, sun_h;
+    // voxel GI (PBRK_SHADE_GI)
+    const uint2* grid; int grid_n;
+    const uint2* prev[8]; int prev_w, prev_h, prev_levels;
+    float vfw[16], cfv[16], vfc[16], wfv[16];   // view_space_from_world, clip_space_from_view, view_space_from_clip, world_space_from_view
+    float lightgrid_scale;
 };
 
 // sampler2DShadow + SAMPLER_PERCENTAGE_CLOSER (render.cpp:664-673: linear, clamp, compare Less): each bilinear tap contributes
@@ -40,7 +45,7 @@ __device__ __forceinline__ float shadow_sample(const float* __restrict__ d, int 
     fy = floorf(fy * 256.0f + 0.5f) * (1.0f / 256.0f);
     float flx = floorf(fx), fly = floorf(fy);
     float a = fx - flx, b = fy - fly;
-    int i0 = (int)flx, j0 = (int)fly;
+    int i0 = (int)fminf(fmaxf(flx, -1.0f), (float)w), j0 = (int)fminf(fmaxf(fly, -1.0f), (float)h);   // float-domain clamp: see snap_split
     int i1 = min(max(i0 + 1, 0), w - 1), j1 = min(max(j0 + 1, 0), h - 1);
     i0 = min(max(i0, 0), w - 1); j0 = min(max(j0, 0), h - 1);
     float c00 = ref < d[j0 * w + i0] ? 1.0f : 0.0f, c10 = ref < d[j0 * w + i1] ? 1.0f : 0.0f;
@@ -152,6 +157,168 @@ __device__ __forceinline__ float2 lut_fetch(const __half2* __restrict__ lut, con
     return r;
 }
 
+// ---- N4: voxel-GI sampling (lighting_pass.glsl:273-424, :546-577).  Branch decisions along the rays (alpha thresholds, ray
+//      behind the visible surface, leaving the screen) must agree with a CPU evaluation, so everything here is the shader's
+//      operation order in correctly rounded fp32, and sin / cos / acos are the fixed polynomials the oracle defines.  EXACT.
+__device__ __forceinline__ void sincos_det(float x, float* sn, float* cs) {
+    float kf = floorf(x * 0.63661977236758134f + 0.5f);
+    float r = fmaf(-kf, 1.5707962512969971f, x);
+    r = fmaf(-kf, 7.5497894158615964e-08f, r);
+    float z = r * r;
+    float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+    float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+    int k = (int)kf & 3;
+    *sn = (k == 0) ? ps : (k == 1) ? pc : (k == 2) ? -ps : -pc;
+    *cs = (k == 0) ? pc : (k == 1) ? -ps : (k == 2) ? -pc : ps;
+}
+__device__ __forceinline__ float asin_poly_det(float x) {
+    float z = x * x;
+    float pp = fmaf(fmaf(fmaf(fmaf(4.2163199048e-2f, z, 2.4181311049e-2f), z, 4.5470025998e-2f), z, 7.4953002686e-2f), z, 1.6666752422e-1f);
+    return fmaf(pp * z, x, x);
+}
+__device__ __forceinline__ float acos_det(float x) {
+    if (x > 0.5f) return 2.0f * asin_poly_det(sqrtf(0.5f * (1.0f - x)));
+    return 1.5707963267948966f - asin_poly_det(x);
+}
+__device__ __forceinline__ void snap_split(float coord01, int extent, int& i0, int& i1, float& a) {
+    float f = coord01 * (float)extent - 0.5f;
+    f = floorf(f * 256.0f + 0.5f) * (1.0f / 256.0f);
+    float fl = floorf(f);
+    a = f - fl;
+    // clamp in the float domain first: a ray that has marched to 1e30 must not reach the float->int conversion (saturation +
+    // `i + 1` would be signed overflow, i.e. an arbitrary index); the clamped indices are the same as clamping the true index
+    int i = (int)fminf(fmaxf(fl, -1.0f), (float)extent);
+    i0 = min(max(i, 0), extent - 1); i1 = min(max(i + 1, 0), extent - 1);
+}
+__device__ __forceinline__ float lerp_x(float a, float b, float t) { return a + t * (b - a); }
+__device__ __forceinline__ float4 unpack_h4(uint2 v) {
+    __half2 lo = *reinterpret_cast<__half2*>(&v.x), hi = *reinterpret_cast<__half2*>(&v.y);
+    float2 a = __half22float2(lo), b = __half22float2(hi);
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+// texture(sampler3D(LIGHTGRID, SAMPLER_LINEAR_CLAMP), p): trilinear, clamp, snapped coordinates
+__device__ __forceinline__ float4 grid_sample(const ShadeParams& p, float px, float py, float pz) {
+    int i0, i1, j0, j1, k0, k1; float a, b, c;
+    const int n = p.grid_n;
+    snap_split(px, n, i0, i1, a); snap_split(py, n, j0, j1, b); snap_split(pz, n, k0, k1, c);
+    float4 t000 = unpack_h4(p.grid[(k0 * n + j0) * n + i0]), t001 = unpack_h4(p.grid[(k0 * n + j0) * n + i1]);
+    float4 t010 = unpack_h4(p.grid[(k0 * n + j1) * n + i0]), t011 = unpack_h4(p.grid[(k0 * n + j1) * n + i1]);
+    float4 t100 = unpack_h4(p.grid[(k1 * n + j0) * n + i0]), t101 = unpack_h4(p.grid[(k1 * n + j0) * n + i1]);
+    float4 t110 = unpack_h4(p.grid[(k1 * n + j1) * n + i0]), t111 = unpack_h4(p.grid[(k1 * n + j1) * n + i1]);
+    float4 r;
+    r.x = lerp_x(lerp_x(lerp_x(t000.x, t001.x, a), lerp_x(t010.x, t011.x, a), b), lerp_x(lerp_x(t100.x, t101.x, a), lerp_x(t110.x, t111.x, a), b), c);
+    r.y = lerp_x(lerp_x(lerp_x(t000.y, t001.y, a), lerp_x(t010.y, t011.y, a), b), lerp_x(lerp_x(t100.y, t101.y, a), lerp_x(t110.y, t111.y, a), b), c);
+    r.z = lerp_x(lerp_x(lerp_x(t000.z, t001.z, a), lerp_x(t010.z, t011.z, a), b), lerp_x(lerp_x(t100.z, t101.z, a), lerp_x(t110.z, t111.z, a), b), c);
+    r.w = lerp_x(lerp_x(lerp_x(t000.w, t001.w, a), lerp_x(t010.w, t011.w, a), b), lerp_x(lerp_x(t100.w, t101.w, a), lerp_x(t110.w, t111.w, a), b), c);
+    return r;
+}
+__device__ __forceinline__ float4 grid_at(const ShadeParams& p, f3 ro) { return grid_sample(p, ro.x * 0.5f + 0.5f, ro.y * 0.5f + 0.5f, ro.z * 0.5f + 0.5f); }
+// one level of PREV_FRAME_RESULT, bilinear clamp with snapped coordinates (xyz only)
+__device__ __forceinline__ f3 prev_level_sample(const ShadeParams& p, int l, float u, float v) {
+    const int w = max(p.prev_w >> l, 1), h = max(p.prev_h >> l, 1);
+    int i0, i1, j0, j1; float a, b;
+    snap_split(u, w, i0, i1, a); snap_split(v, h, j0, j1, b);
+    const uint2* t = p.prev[l];
+    float4 t00 = unpack_h4(t[j0 * w + i0]), t10 = unpack_h4(t[j0 * w + i1]), t01 = unpack_h4(t[j1 * w + i0]), t11 = unpack_h4(t[j1 * w + i1]);
+    return mk3(lerp_x(lerp_x(t00.x, t10.x, a), lerp_x(t01.x, t11.x, a), b), lerp_x(lerp_x(t00.y, t10.y, a), lerp_x(t01.y, t11.y, a), b),
+               lerp_x(lerp_x(t00.z, t10.z, a), lerp_x(t01.z, t11.z, a), b));
+}
+__device__ __forceinline__ f3 luminance_normalise(float x, float y, float z) {            // :267-269, :314-316, :420-422
+    float luminance = 0.299f * x + 0.587f * y + 0.114f * z;
+    float k = sqrtf(luminance) / fmaxf(luminance, 0.0001f);
+    return mk3(x * k, y * k, z * k);
+}
+// lighting_pass.glsl:273-424 SampleRadianceWithScreenSpaceTrace
+__device__ __forceinline__ f3 sample_radiance_ss(const ShadeParams& p, f3 V, const float* p0_vs, f3 ray_origin, f3 ray_direction,
+                                              int num_steps, float step_scale, float noise_01, float foggyness, float ss_intensity) {
+    const float voxel_scale = 2.0f / 128.0f;                                              // :274
+    const float ls = p.lightgrid_scale;
+    f3 rd = scale3(ray_direction, voxel_scale);
+    f3 ro = scale3(ray_origin, ls);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0001f;
+    for (int i = 0; i < 4; ++i) {                                                         // :281-288
+        ro = add3(ro, rd);
+        float4 rad = grid_at(p, ro);
+        if (rad.w < 0.3f) { s0 += rad.x; s1 += rad.y; s2 += rad.z; s3 += 1.0f; break; }
+    }
+    float open_vs[4];
+    mat_mul(p.vfw, ro.x / ls, ro.y / ls, ro.z / ls, 1.0f, open_vs);                       // :290
+    const float d0 = open_vs[0] - p0_vs[0], d1 = open_vs[1] - p0_vs[1], d2 = open_vs[2] - p0_vs[2];   // :298
+    float step_length = fmaxf(p0_vs[2], 1.0f) * (1.0f + noise_01) / 100.0f;               // :300
+    const float lxy = sqrtf(d0 * d0 + d1 * d1);
+    f3 ssray_step = scale3(mk3(d0 / lxy, d1 / lxy, d2 / lxy), step_length);               // :301-302
+    f3 pos = mk3(p0_vs[0], p0_vs[1], p0_vs[2]);
+    const float dist_to_travel = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);                      // :308
+    float dist_travelled = 0.0f;
+    for (int guard = 0; guard < 512; ++guard) {                                           // :315 for (;;): every wave reaches an exit (steps grow >= 1.2x)
+        pos = add3(pos, ssray_step);
+        dist_travelled += step_length;
+        float ndc[4];
+        mat_mul(p.cfv, pos.x, pos.y, pos.z, 1.0f, ndc);                                   // :319-320
+        const float nw = ndc[3];
+        ndc[0] = ndc[0] / nw; ndc[1] = ndc[1] / nw;
+        if (fminf(fmaxf(ndc[0], -1.0f), 1.0f) != ndc[0] || fminf(fmaxf(ndc[1], -1.0f), 1.0f) != ndc[1]) {   // :322-330
+            float4 s4 = grid_at(p, mk3(ray_origin.x * ls + 2.5f * V.x * voxel_scale, ray_origin.y * ls + 2.5f * V.y * voxel_scale,
+                                       ray_origin.z * ls + 2.5f * V.z * voxel_scale));
+            return luminance_normalise(s4.x, s4.y, s4.z);
+        }
+        ssray_step = scale3(ssray_step, 1.2f); step_length *= 1.2f;                       // :332-333
+        const float su = ndc[0] * 0.5f + 0.5f, sv = ndc[1] * 0.5f + 0.5f;
+        const int di = min(max((int)fminf(fmaxf(floorf(su * (float)p.width), 0.0f), (float)p.width), 0), p.width - 1);
+        const int dj = min(max((int)fminf(fmaxf(floorf(sv * (float)p.height), 0.0f), (float)p.height), 0), p.height - 1);
+        const float depth_ndc = p.depth[(size_t)dj * p.width + di];                       // :335 SAMPLER_NEAREST_CLAMP
+        float surf[4];
+        mat_mul(p.vfc, ndc[0], ndc[1], depth_ndc, 1.0f, surf);                            // :338-339
+        const float sw = surf[3];
+        surf[0] = surf[0] / sw; surf[1] = surf[1] / sw; surf[2] = surf[2] / sw; surf[3] = surf[3] / sw;
+        const float ls_surf = sqrtf(surf[0] * surf[0] + surf[1] * surf[1] + surf[2] * surf[2]);
+        const float ls_pos = sqrtf(pos.x * pos.x + pos.y * pos.y + pos.z * pos.z);
+        if (ls_surf < ls_pos) {                                                           // :343
+            float ts[4], te[4];
+            mat_mul(p.wfv, surf[0], surf[1], surf[2], surf[3], ts);                       // :348-349
+            mat_mul(p.wfv, pos.x, pos.y, pos.z, 1.0f, te);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { ts[k] = ts[k] * ls * 0.5f + 0.5f; te[k] = te[k] * ls * 0.5f + 0.5f; }
+            const float noise_offset = noise_01 * 0.2f;                                   // :351
+            float alpha = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {                                                 // :352-355
+                const float t = noise_offset + (k == 0 ? 0.2f : (k == 1 ? 0.4f : 0.6f));
+                float4 r4 = grid_sample(p, mix_(ts[0], te[0], t), mix_(ts[1], te[1], t), mix_(ts[2], te[2], t));
+                alpha = (k == 0) ? r4.w : alpha + r4.w;
+            }
+            if (alpha < 1.5f) {                                                           // :357-361
+                const float f = 2.0f + noise_01;
+                ssray_step = scale3(ssray_step, f); step_length *= f;
+                continue;
+            }
+            float lod = fminf(fmaxf(fminf(step_length * 5.0f, 5.0f), 0.0f), (float)(p.prev_levels - 1));   // :380, clamped to the chain
+            const float fl = floorf(lod);
+            const int l0 = (int)fl;
+            const float w = lod - fl;
+            f3 c = prev_level_sample(p, l0, su, sv);
+            if (w > 0.0f) {
+                f3 c1 = prev_level_sample(p, min(l0 + 1, p.prev_levels - 1), su, sv);
+                c = mk3(lerp_x(c.x, c1.x, w), lerp_x(c.y, c1.y, w), lerp_x(c.z, c1.z, w));
+            }
+            return mk3(c.x * ss_intensity, c.y * ss_intensity, c.z * ss_intensity);       // :382
+        }
+        if (dist_travelled > dist_to_travel) break;                                       // :393
+    }
+    if (s3 < 0.5f) return mk3(0.0f, 0.0f, 0.0f);                                          // :400-403
+    rd = scale3(rd, step_scale);                                                          // :407-408
+    ro = mk3(ro.x + rd.x * noise_01, ro.y + rd.y * noise_01, ro.z + rd.z * noise_01);
+    for (int i = 0; i < num_steps; ++i) {                                                 // :411-419
+        ro = mk3(ro.x + 0.5f * rd.x, ro.y + 0.5f * rd.y, ro.z + 0.5f * rd.z);
+        float4 rad = grid_at(p, ro);
+        if (rad.w > 0.3f) break;
+        s0 = s0 * foggyness + rad.x; s1 = s1 * foggyness + rad.y; s2 = s2 * foggyness + rad.z; s3 = s3 * foggyness + 1.0f;
+    }
+    return luminance_normalise(s0 / s3, s1 / s3, s2 / s3);                                // :421-423
+}
+
+// kGI: the voxel-GI traces need ~250 VGPRs; the common modes keep their own instantiation (54 VGPRs)
+template <bool kGI>
 __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
     __shared__ int level_tab[32];
     fill_level_table(level_tab, p.pre_size, min(p.pre_levels, 16), p.pre_cells_first);
@@ -256,7 +423,7 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
             {
                 f3 L = mk3(-p.sun[0], -p.sun[1], -p.sun[2]);
                 f3 Hs = add3(L, V);
-                f3 H = scale3(Hs, __builtin_amdgcn_rsqf(dot3(Hs, Hs)));      // feeds continuous terms only: 1-ulp rsq
+                f3 H = normalize3(Hs);        // exact: the GGX lobe amplifies an error in N.H by 1/a^2 (1300x at roughness 1/6)
                 float NdotL = fmaxf(dot3(N, L), 0.0f);
                 if (NdotL > 0.0f) {
                     float VdotH = fmaxf(dot3(V, H), 0.0f);
@@ -273,16 +440,35 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
                 }
             }
 
-            if (p.flags & PBRK_SHADE_IBL) {
+            const bool gi = kGI;
+            if ((p.flags & PBRK_SHADE_IBL) || gi) {
                 float2 sb = lut_fetch(p.lut, p.lut_cells, p.lut_size, VdotN, fmaxf(roughness, 0.05f));  // :681
-                f3 irr;                                                                    // :690
-                {
+                f3 ambient = mk3(0.0f, 0.0f, 0.0f);
+                if (p.flags & PBRK_SHADE_IBL) {                                            // :690 (commented line)
                     CubeTap tp = cube_tap<true>(N, p.irr_size);
-                    irr = p.irr_cells ? fetch_rgb_cells_tap(p.irr_cells, p.irr_size, tp) : fetch_rgb_tap(p.irr, p.irr_size, tp);
+                    ambient = p.irr_cells ? fetch_rgb_cells_tap(p.irr_cells, p.irr_size, tp) : fetch_rgb_tap(p.irr, p.irr_size, tp);
                 }
-                outl.x += kD.x * irr.x * base.x;                                           // :687
-                outl.y += kD.y * irr.y * base.y;
-                outl.z += kD.z * irr.z * base.z;
+                float p0_view[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+                if (gi) {
+                    float pv[4];
+                    mat_mul(p.vfc, fs_u * 2.0f - 1.0f, fs_v * 2.0f - 1.0f, depth, 1.0f, pv);   // :446-447
+                    p0_view[0] = pv[0] / pv[3]; p0_view[1] = pv[1] / pv[3]; p0_view[2] = pv[2] / pv[3]; p0_view[3] = pv[3] / pv[3];
+                    // :546-577 random direction in the hemisphere around N
+                    f3 some_vector = normalize3(mk3(0.7128864983f, 0.8217892113f, 0.948912748f));
+                    f3 tangent = normalize3(cross3(some_vector, N));
+                    f3 bitangent = cross3(N, tangent);
+                    float pitch = acos_det(sqrtf(1.0f - noise_1));
+                    float yaw = (2.0f * PBR_PI) * noise_3;
+                    float sp_, cp_, sy_, cy_;
+                    sincos_det(pitch, &sp_, &cp_); sincos_det(yaw, &sy_, &cy_);
+                    float lx = sp_ * cy_, ly = sp_ * sy_, lz = cp_;
+                    f3 bent = mk3((tangent.x * lx + bitangent.x * ly) + N.x * lz, (tangent.y * lx + bitangent.y * ly) + N.y * lz,
+                                  (tangent.z * lx + bitangent.z * ly) + N.z * lz);
+                    ambient = sample_radiance_ss(p, V, p0_view, P, bent, 12, 1.0f, noise_3, 0.5f, 0.75f);   // :685
+                }
+                outl.x += kD.x * ambient.x * base.x;                                       // :687
+                outl.y += kD.y * ambient.y * base.y;
+                outl.z += kD.z * ambient.z * base.z;
                 // :693-697
                 f3 I = mk3(-V.x, -V.y, -V.z);
                 float dNI = dot3(N, I);
@@ -292,7 +478,9 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
                 float r2 = roughness * roughness;
                 float r4 = r2 * r2;
                 R = mk3(mix_(R.x, N.x, r4), mix_(R.y, N.y, r4), mix_(R.z, N.z, r4));
-                f3 spec = pyramid_fetch(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, R, roughness * 4.0f, level_tab);   // :699
+                f3 spec = mk3(0.0f, 0.0f, 0.0f);
+                if (p.flags & PBRK_SHADE_IBL) spec = pyramid_fetch(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, R, roughness * 4.0f, level_tab);   // :699
+                if (gi) spec = sample_radiance_ss(p, V, p0_view, P, R, 16, 2.0f, noise_3, roughness, 0.9f);   // :701
                 outl.x += spec.x * (F0.x * sb.x + sb.y);                                   // :702
                 outl.y += spec.y * (F0.y * sb.x + sb.y);
                 outl.z += spec.z * (F0.z * sb.x + sb.y);
@@ -342,6 +530,11 @@ extern "C" int pbrk_shade(const PbrkShadeArgs* a, void* stream) {
     if (a->flags & PBRK_SHADE_IBL) {
         if (!a->irradiance_bordered || a->irradiance_size < 1 || !a->lut || a->lut_size < 1) return PBRK_E_ARG;
     }
+    if (a->flags & PBRK_SHADE_GI) {
+        if (!a->lightgrid || a->lightgrid_size < 1 || a->lightgrid_size > 1024 || !a->lut || a->lut_size < 1) return PBRK_E_ARG;
+        if (a->prev_frame_levels < 1 || a->prev_frame_levels > 8 || a->prev_frame_w < 1 || a->prev_frame_h < 1) return PBRK_E_ARG;
+        for (int l = 0; l < a->prev_frame_levels; ++l) if (!a->prev_frame[l]) return PBRK_E_ARG;
+    }
     if (a->flags & PBRK_SHADE_SHADOWS) {
         if (!a->sun_depth || a->sun_depth_w < 1 || a->sun_depth_h < 1 || (long long)a->sun_depth_w * a->sun_depth_h > (1ll << 30)) return PBRK_E_ARG;
     }
@@ -358,8 +551,14 @@ extern "C" int pbrk_shade(const PbrkShadeArgs* a, void* stream) {
     for (int i = 0; i < 16; ++i) { p.wfc[i] = a->globals[32 + i]; p.ssw[i] = a->globals[96 + i]; }
     for (int i = 0; i < 3; ++i) { p.sun[i] = a->globals[128 + i]; p.cam[i] = a->globals[132 + i]; }
     p.frame_idx_mod_59 = a->globals[135];
+    p.grid = (const uint2*)a->lightgrid; p.grid_n = a->lightgrid_size;
+    for (int l = 0; l < 8; ++l) p.prev[l] = (const uint2*)a->prev_frame[l];
+    p.prev_w = a->prev_frame_w; p.prev_h = a->prev_frame_h; p.prev_levels = a->prev_frame_levels;
+    for (int i = 0; i < 16; ++i) { p.cfv[i] = a->globals[16 + i]; p.vfc[i] = a->globals[48 + i]; p.vfw[i] = a->globals[64 + i]; p.wfv[i] = a->globals[80 + i]; }
+    p.lightgrid_scale = a->globals[136];
     p.sun_depth = (const float*)a->sun_depth; p.sun_w = a->sun_depth_w; p.sun_h = a->sun_depth_h;
     p.rcp_width = 1.0f / (float)a->width; p.rcp_height = 1.0f / (float)a->height;
-    hipLaunchKernelGGL(k_shade, dim3((p.w + 63) / 64, (p.h + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    if (a->flags & PBRK_SHADE_GI) hipLaunchKernelGGL(k_shade<true>, dim3((p.w + 63) / 64, (p.h + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(k_shade<false>, dim3((p.w + 63) / 64, (p.h + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }

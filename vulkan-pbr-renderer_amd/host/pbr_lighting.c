@@ -190,6 +190,11 @@ PBR_LightingPass* PBR_MakeLightingPass(const PBR_GBuffer* gb, const PBR_IBLMaps*
 }
 
 PBR_LightingPass* PBR_MakeLightingPassEx(const PBR_GBuffer* gb, const PBR_IBLMaps* maps, uint32_t width, uint32_t height, GPU_Texture* sun_depth_map) {
+    return PBR_MakeLightingPassLive(gb, maps, width, height, sun_depth_map, NULL, NULL);
+}
+
+PBR_LightingPass* PBR_MakeLightingPassLive(const PBR_GBuffer* gb, const PBR_IBLMaps* maps, uint32_t width, uint32_t height,
+                                           GPU_Texture* sun_depth_map, GPU_Texture* lightgrid, GPU_Texture* prev_frame_result) {
     PBR_LightingPass* lp = (PBR_LightingPass*)calloc(1, sizeof *lp);
     /* render.cpp:664-675 */
     GPU_SamplerDesc pcf; memset(&pcf, 0, sizeof pcf);
@@ -252,8 +257,8 @@ PBR_LightingPass* PBR_MakeLightingPassEx(const PBR_GBuffer* gb, const PBR_IBLMap
     GPU_SetTextureBinding(s, irr_b, maps->irradiance_map);
     GPU_SetTextureBinding(s, pre_b, maps->tex_specular_env_map);
     GPU_SetTextureBinding(s, lut_b, maps->brdf_lut);
-    GPU_SetTextureBinding(s, grid_b, lp->dummy3d);
-    GPU_SetTextureBinding(s, prev_b, lp->dummy2d);
+    GPU_SetTextureBinding(s, grid_b, lightgrid ? lightgrid : lp->dummy3d);                      /* render.cpp:861 r->lightgrid */
+    GPU_SetTextureBinding(s, prev_b, prev_frame_result ? prev_frame_result : lp->dummy2d);      /* render.cpp:862 bloom_downscale_rt */
     GPU_SetTextureBinding(s, sun_b, sun_depth_map ? sun_depth_map : lp->dummy_depth);            /* render.cpp:676 sun_depth_rt */
     GPU_SetSamplerBinding(s, s_lc, GPU_SamplerLinearClamp());
     GPU_SetSamplerBinding(s, s_lw, GPU_SamplerLinearWrap());

@@ -94,7 +94,7 @@ class PbrkFinalArgs(C.Structure):
                 ("y0", C.c_int), ("y1", C.c_int)]
 
 
-Shade_IBL, Shade_LightShafts, Shade_SunShadows = 1, 2, 4
+Shade_IBL, Shade_LightShafts, Shade_SunShadows, Shade_VoxelGI = 1, 2, 4, 8
 PBRK_FMT_RG16F, PBRK_FMT_RG32F, PBRK_FMT_RGBA16F, PBRK_FMT_RGBA32F, PBRK_FMT_R32F, PBRK_FMT_RGBA8UN, PBRK_FMT_BGRA8UN = 1, 2, 3, 4, 5, 6, 7
 
 
@@ -106,6 +106,8 @@ class PbrkShadeArgs(C.Structure):
                 ("lut", C.c_void_p), ("lut_size", C.c_int), ("irradiance_cells", C.c_void_p), ("prefiltered_cells", C.c_void_p),
                 ("prefiltered_cells_first", C.c_int), ("lut_cells", C.c_void_p),
                 ("sun_depth", C.c_void_p), ("sun_depth_w", C.c_int), ("sun_depth_h", C.c_int),
+                ("lightgrid", C.c_void_p), ("lightgrid_size", C.c_int), ("prev_frame", C.c_void_p * 8),
+                ("prev_frame_w", C.c_int), ("prev_frame_h", C.c_int), ("prev_frame_levels", C.c_int),
                 ("out", C.c_void_p), ("out_format", C.c_int), ("flags", C.c_int),
                 ("globals", C.c_float * 138)]
 
@@ -181,6 +183,7 @@ PROTOTYPES = {
     "PBR_MakeGBuffer": (None, [C.POINTER(PBR_GBuffer), U32, U32, C.c_int]), "PBR_DestroyGBuffer": (None, [C.POINTER(PBR_GBuffer)]),
     "PBR_MakeLightingPass": (VP, [C.POINTER(PBR_GBuffer), C.POINTER(PBR_IBLMaps), U32, U32]), "PBR_DestroyLightingPass": (None, [VP]),
     "PBR_MakeLightingPassEx": (VP, [C.POINTER(PBR_GBuffer), C.POINTER(PBR_IBLMaps), U32, U32, TexP]),
+    "PBR_MakeLightingPassLive": (VP, [C.POINTER(PBR_GBuffer), C.POINTER(PBR_IBLMaps), U32, U32, TexP, TexP, TexP]),
     "PBR_LightingGlobalsBuffer": (BufP, [VP]), "PBR_LightingPipeline": (VP, [VP]),
     "PBR_RecordLightingPass": (None, [VP, VP, C.POINTER(PBR_Globals), U32, U32]),
     "PBR_MakePostProcess": (VP, [C.POINTER(PBR_GBuffer), U32, U32, C.c_int]), "PBR_DestroyPostProcess": (None, [VP]),

@@ -450,3 +450,61 @@ def synth_sun_depth(size=2048, seed=0x5EED00E0):
         w, h = 0.05 + rng.random(2) * 0.15
         d[(u > x0) & (u < x0 + w) & (v > y0) & (v < y0 + h)] = 0.05 + 0.2 * rng.random()
     return d.astype(np.float32)
+
+
+GI_SCENE_CAMERA = (0.0, -5.5, 0.0)   # close enough that the sphere grid overflows the screen (rays leave it: the off-screen exit)
+GI_SCENE_EXTENT = 8.0        # half-size of the world cube the test scene's light grid covers (the reference uses 40: render.cpp:960)
+
+
+def synth_gi_scene(width, height, seed=0x5EED00F0, grid_size=128):
+    """Inputs of the complete live lighting shader around the metal-rough-spheres G-buffer: a light grid with the spheres, a back
+    wall and a floor voxelised into it (occupied voxels: alpha 1, lit surface colour; empty voxels: a smooth glow, as after a
+    few sweeps), the 'previous frame' mip chain (half resolution, like bloom_downscale_rt) and a sun depth map with fine ripples
+    around the scene's depth as the sun sees it.  Returns (gbuffer dict, grid float16 [n][n][n][4], prev levels, sun float32)."""
+    rng = np.random.default_rng(seed)
+    gbd = synth_gbuffer_spheres(width, height, cam_pos=GI_SCENE_CAMERA)
+    n = grid_size
+    c = ((np.arange(n) + 0.5) / n * 2 - 1) * GI_SCENE_EXTENT
+    Z, Y, X = np.meshgrid(c, c, c, indexing="ij")                     # grid[z][y][x]
+    grid = np.zeros((n, n, n, 4), np.float16)
+    glow = 0.35 + 0.25 * np.sin(0.9 * X + 0.4) * np.cos(0.7 * Z) + 0.15 * np.sin(1.3 * Y)
+    grid[..., 0] = (glow * 1.0).astype(np.float16); grid[..., 1] = (glow * 0.9).astype(np.float16); grid[..., 2] = (glow * 1.2).astype(np.float16)
+    occ = np.zeros((n, n, n), bool)
+    col = np.zeros((n, n, n, 3))
+    for row in range(7):
+        for cl in range(7):
+            ctr = np.array([(cl - 3) * 1.3, 0.0, (3 - row) * 1.3])
+            inside = (X - ctr[0]) ** 2 + (Y - ctr[1]) ** 2 + (Z - ctr[2]) ** 2 < 0.55 ** 2
+            occ |= inside
+            col[inside] = PALETTE[(row + cl) % 7] * 1.5
+    for (bx, bz, half) in ((-3.9, 3.9, 1.3), (2.6, -2.6, 0.9)):            # two spheres sit inside solid blocks: no open point in 4 steps
+        blk = (np.abs(X - bx) < half) & (np.abs(Y) < half) & (np.abs(Z - bz) < half)
+        occ |= blk
+        col[blk] = (0.5, 0.45, 0.4)
+    wall = (Y > 2.0) & (Y < 2.6)
+    floor = Z < -4.9
+    occ |= wall | floor
+    col[wall] = (0.8, 0.75, 0.6); col[floor] = (0.3, 0.35, 0.3)
+    grid[occ, :3] = col[occ].astype(np.float16)
+    grid[..., 3] = occ
+    soft = (rng.random((n, n, n)) < 0.003) & ~occ                     # a few half-dense voxels around the 0.3 alpha thresholds
+    grid[soft, 3] = rng.choice([0.25, 0.35, 0.5], int(soft.sum())).astype(np.float16)
+    # previous frame: half-resolution RGBA16F image + box-filtered mips
+    pw, ph = max(1, width // 2), max(1, height // 2)
+    yy, xx = np.mgrid[0:ph, 0:pw].astype(np.float64)
+    img = np.stack([0.6 + 0.4 * np.sin(xx * 0.31), 0.5 + 0.4 * np.cos(yy * 0.27), 0.4 + 0.3 * np.sin((xx + yy) * 0.19), np.ones_like(xx)], -1)
+    levels = [img.astype(np.float16)]
+    while levels[-1].shape[0] > 1 or levels[-1].shape[1] > 1:
+        a = levels[-1].astype(np.float32)
+        h2, w2 = max(1, a.shape[0] // 2), max(1, a.shape[1] // 2)
+        a = a[: h2 * 2 if a.shape[0] > 1 else 1, : w2 * 2 if a.shape[1] > 1 else 1]
+        if a.shape[0] > 1:
+            a = 0.5 * (a[0::2] + a[1::2])
+        if a.shape[1] > 1:
+            a = 0.5 * (a[:, 0::2] + a[:, 1::2])
+        levels.append(a.astype(np.float16))
+        if len(levels) == 6:
+            break
+    v, u = np.mgrid[0:512, 0:512] / 512.0
+    sun = (0.5 + 0.08 * np.sin(2 * np.pi * 40 * u) * np.cos(2 * np.pi * 36 * v)).astype(np.float32)
+    return gbd, grid, levels, sun
