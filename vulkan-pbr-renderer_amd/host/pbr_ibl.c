@@ -186,6 +186,23 @@ static double samples_per_texel(uint32_t mip) {
     return 8192.0;
 }
 
+/* Measured time per sample-evaluation relative to mip 2 (one MI355X, C4): the MC kernel is a little faster where
+ * most weights are large (mip 1) and slower where levels are small; the irradiance pass reads a tiny level.  The copy mip moves
+ * 16 B per texel at ~3.4 TB/s, i.e. as long as ~3.8 sample-evaluations per texel.  Used for balancing only; unit.cost stays
+ * the plain count. */
+static double time_weight(const PBR_WorkUnit* u) {
+    if (u->kind == PBR_Unit_Irradiance) return 1.24;
+    switch (u->mip) {
+    case 0: return 3.8;
+    case 1: return 0.965;
+    case 2: return 1.0;
+    case 3: return 1.04;
+    case 4: return 1.13;
+    case 5: return 1.07;
+    default: return 1.1;
+    }
+}
+
 static int cmp_cost_desc(const void* a, const void* b) {
     double ca = ((const PBR_WorkUnit*)a)->cost, cb = ((const PBR_WorkUnit*)b)->cost;
     if (ca != cb) return ca < cb ? 1 : -1;
@@ -268,8 +285,7 @@ uint32_t PBR_PartitionIBL(uint32_t specular_size, uint32_t min_size, uint32_t ir
             if ((pass == 0) != pinned) continue;
             int best = 0;
             if (!pinned) for (int r = 1; r < world; ++r) if (load[r] < load[best]) best = r;
-            /* the copy mip is bandwidth work: charge it at its byte cost relative to a Monte-Carlo sample (~1 sample / 48 B) */
-            load[best] += pinned ? all[k].cost * 16.0 : all[k].cost;
+            load[best] += all[k].cost * time_weight(&all[k]);
             if (rank < 0 || best == rank) {
                 if (written < capacity && out) out[written] = all[k];
                 ++written;
