@@ -153,6 +153,15 @@ def test_gpu_sweep_full_grid_frames(gpu):
         L.GPU_GraphSubmit(g); L.GPU_GraphWait(g); L.GPU_DestroyGraph(g)
         got = pbrhip.read_mip(tex, 0).view(np.uint16)
         assert np.array_equal(got, full), f"sharded direction {direction}"
+        # odd range boundaries: tiles start on odd voxels (the kernel's 8-byte store path) and end in partial tiles
+        pbrhip.upload_mip(tex, 0, start)
+        g = L.GPU_MakeGraph()
+        L.PBR_RecordLightgridSweepLines(lg, g, direction, 0, 128, 0, 41)
+        L.PBR_RecordLightgridSweepLines(lg, g, direction, 0, 73, 41, 128)
+        L.PBR_RecordLightgridSweepLines(lg, g, direction, 73, 128, 41, 128)
+        L.GPU_GraphSubmit(g); L.GPU_GraphWait(g); L.GPU_DestroyGraph(g)
+        got = pbrhip.read_mip(tex, 0).view(np.uint16)
+        assert np.array_equal(got, full), f"sharded (odd boundaries) direction {direction}"
     L.PBR_DestroyLightgrid(lg)
 
 

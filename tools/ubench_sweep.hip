@@ -7,6 +7,9 @@
 #include <algorithm>
 #include <map>
 
+__global__ __launch_bounds__(256) void k_empty_lds(int* out) { extern __shared__ int sm[]; if (out && threadIdx.x == 999) out[0] = sm[0]; }
+__global__ __launch_bounds__(256) void k_empty(int* out) { if (out && threadIdx.x == 999) out[0] = 1; }
+
 int main() {
     const int n = 128;
     size_t vox = (size_t)n * n * n;
@@ -21,6 +24,17 @@ int main() {
     unsigned long long* prof; hipMalloc(&prof, 256 * 16 * 8); hipMemset(prof, 0, 256 * 16 * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_prof), &prof, sizeof prof);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    {   // launch + drain cost of this grid shape without any work: 256 workgroups x 256 threads, with and without 65 KB of LDS each
+        hipFuncSetAttribute((const void*)k_empty_lds, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        for (int with_lds = 0; with_lds < 2; ++with_lds) {
+            for (int rep = 0; rep < 3; ++rep) { if (with_lds) hipLaunchKernelGGL(k_empty_lds, dim3(2, 128), dim3(256), kLdsBytes, 0, (int*)nullptr); else hipLaunchKernelGGL(k_empty, dim3(2, 128), dim3(256), 0, 0, (int*)nullptr); }
+            hipEventRecord(a);
+            for (int rep = 0; rep < 50; ++rep) { if (with_lds) hipLaunchKernelGGL(k_empty_lds, dim3(2, 128), dim3(256), kLdsBytes, 0, (int*)nullptr); else hipLaunchKernelGGL(k_empty, dim3(2, 128), dim3(256), 0, 0, (int*)nullptr); }
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            printf("empty kernel, 256 WGs x 256 threads, %s: %.2f us/launch back-to-back\n", with_lds ? "65 KB LDS each" : "no LDS", ms * 1e3 / 50);
+        }
+    }
     for (int dir = 0; dir < 3; ++dir) {
         for (int rep = 0; rep < 3; ++rep) pbrk_lightgrid_sweep(d, n, n, n, dir, 0, n, 0, n, nullptr);
         hipEventRecord(a);
@@ -30,12 +44,13 @@ int main() {
         std::vector<unsigned long long> p(256 * 16);
         hipMemcpy(p.data(), prof, p.size() * 8, hipMemcpyDeviceToHost);
         unsigned long long t0 = ~0ull, t1 = 0;
-        double ph[6] = {0, 0, 0, 0, 0, 0}, cyc[6] = {0, 0, 0, 0, 0, 0};
+        double fwd_ns = 0, all_ns = 0, fwd_clk = 0, all_clk = 0;                 // stamps: 0 start, 3 forward sweep done (wave 0), 6 end
         std::map<unsigned long long, int> place;
         for (int blk = 0; blk < 256; ++blk) {
             unsigned long long* q = &p[blk * 16];
             t0 = std::min(t0, q[0]); t1 = std::max(t1, q[6]);
-            for (int k = 0; k < 6; ++k) { ph[k] += (double)(q[k + 1] - q[k]) * 10.0 / 256; cyc[k] += (double)(q[8 + k + 1] - q[8 + k]) / 256; }
+            fwd_ns += (double)(q[3] - q[0]) * 10.0 / 256; all_ns += (double)(q[6] - q[0]) * 10.0 / 256;
+            fwd_clk += (double)(q[8 + 3] - q[8 + 0]) / 256; all_clk += (double)(q[8 + 6] - q[8 + 0]) / 256;
             unsigned hw = (unsigned)q[7]; unsigned xcc = (unsigned)(q[7] >> 32) & 0xf;
             unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 0x7;
             place[((unsigned long long)xcc << 16) | (se << 8) | (sh << 4) | cu]++;
@@ -43,8 +58,7 @@ int main() {
         int multi = 0; for (auto& kv : place) multi += kv.second > 1;
         printf("dir %d: %.2f us/launch back-to-back; last launch span %.2f us; distinct CUs %zu (CUs with >1 block: %d)\n", dir, ms * 1e3 / 20,
                (double)(t1 - t0) * 10.0 / 1e3, place.size(), multi);
-        printf("   mean phase ns  : load %.0f | barrier %.0f | forward %.0f | backward %.0f | barrier %.0f | store %.0f\n", ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
-        printf("   mean phase clk : load %.0f | barrier %.0f | forward %.0f | backward %.0f | barrier %.0f | store %.0f\n", cyc[0], cyc[1], cyc[2], cyc[3], cyc[4], cyc[5]);
+        printf("   mean per block: loads + forward sweep %.0f ns (%.0f clk) | whole block %.0f ns (%.0f clk)\n", fwd_ns, fwd_clk, all_ns, all_clk);
     }
     return 0;
 }

@@ -27,13 +27,14 @@ namespace {
 constexpr int kLen = PBRK_SWEEP_LEN;     // voxels per line (the shader's array size)
 constexpr int kTile = 64;                // lines per block
 constexpr int kPitch = kTile + 1;        // LDS row pitch in voxels
-constexpr int kLdsBytes = kLen * kPitch * 8;
+constexpr int kLdsBytes = kLen * kPitch * 8 + 16;   // tile + the backward sweep's progress counter
 
 struct SweepGeom {
     long long base;                      // voxel offset of line (f0, s0), step 0
     long long fstride, sstride, xstride; // voxel strides: next line in the tile, next tile row, next step along the line
     int nf;                              // lines in the fast dimension (tiles are cut from it)
     int contiguous_lines;                // 1: xstride == 1 (sweep along x), 0: fstride == 1
+    int pair_stores;                     // 1: every (even voxel, next voxel) pair of a tile row is 16-B aligned in memory
 };
 
 #ifdef PBRK_SWEEP_PROFILE      // tools/ubench_sweep.hip only: per-block phase timestamps (wave 0) + placement
@@ -45,8 +46,26 @@ __device__ unsigned long long* g_sweep_prof;
 #define SWEEP_STAMP(k) do {} while (0)
 #endif
 
+// streaming store: the swept voxels are not read again by this kernel, and a write-back L2 would otherwise hold all 16 MiB
+// until the end-of-kernel release flushes them in one exposed burst
+__device__ __forceinline__ void store_stream(uint2* p, uint2 v) {
+    __builtin_nontemporal_store(((unsigned long long)v.y << 32) | v.x, (unsigned long long*)p);
+}
+
+__device__ __forceinline__ void store_stream2(uint2* p, uint2 v0, uint2 v1) {      // two adjacent voxels, 16-B aligned
+    typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
+    u32x4n q = {v0.x, v0.y, v1.x, v1.y};
+    __builtin_nontemporal_store(q, (u32x4n*)p);
+}
+
 __device__ __forceinline__ float half_bits_to_float(unsigned h) { return __half2float(__ushort_as_half((unsigned short)h)); }
 
+// Streamed form: the line is cut into 8 chunks of 16 steps.  All loads are issued up front, in chunk order; chunk c is written to
+// LDS and released by a barrier as soon as it has landed, so the forward sweep of chunk c runs while chunks c+1.. are still in
+// flight.  The backward sweep releases each finished chunk to wave 3 (which has no channel to sweep), and wave 3 streams it
+// back to HBM while waves 0-2 continue down the line.  The memory phases (2.4 us + 4 us when run back to back) hide under the
+// 7.5 us dependent chain.
+template <bool kContig>      // kContig: lines run along x (each line is contiguous); else adjacent lines are adjacent voxels
 __global__ __launch_bounds__(256) void k_lightgrid_sweep(uint2* __restrict__ img, SweepGeom g) {
     extern __shared__ uint2 tile[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -54,118 +73,152 @@ __global__ __launch_bounds__(256) void k_lightgrid_sweep(uint2* __restrict__ img
     const int nvalid = min(kTile, g.nf - f0);
     uint2* base = img + g.base + (long long)blockIdx.y * g.sstride + (long long)f0 * g.fstride;
     SWEEP_STAMP(0);
+    constexpr int kChunk = 16, kChunks = kLen / kChunk;
 
-    // ---- stage the tile: 32 x 8-B loads per thread, 512 B contiguous per wave-level load in every direction
-    {
-        uint2 v[32];
+    // ---- loads, chunk-major: 4 voxels per thread and chunk.
+    //      lines along x (contiguous): thread -> (line t>>2, 4 consecutive voxels): 2 x 16 B, 128 B per line and chunk;
+    //      lines along y / z: thread -> (line = lane, steps wave + 4j): 4 x 8 B, 512 B rows across the lanes.
+    //      Loads are unconditional (lines beyond a partial tile re-read its last line; only stores are predicated), so that
+    //      nothing but the data dependence orders them: the compiler's vmcnt waits then release chunk after chunk.
+    uint2 v[kChunks][4];
+    const int ll = min(kContig ? (t >> 2) : lane, nvalid - 1);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {                                        // all 32 loads in flight: one memory round trip
-            int item = wave + 4 * i, l, x;
-            if (g.contiguous_lines) { l = item >> 1; x = lane + 64 * (item & 1); }
-            else { l = lane; x = item; }
-            v[i] = make_uint2(0u, 0u);
-            if (l < nvalid) v[i] = base[(long long)l * g.fstride + (long long)x * g.xstride];
-        }
+    for (int c = 0; c < kChunks; ++c) {
+        if (kContig) {
+            const uint4* p = (const uint4*)(base + (long long)ll * g.fstride + (c * kChunk + (t & 3) * 4));
+            uint4 a = p[0], b = p[1];
+            v[c][0] = make_uint2(a.x, a.y); v[c][1] = make_uint2(a.z, a.w); v[c][2] = make_uint2(b.x, b.y); v[c][3] = make_uint2(b.z, b.w);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            int item = wave + 4 * i, l, x;
-            if (g.contiguous_lines) { l = item >> 1; x = lane + 64 * (item & 1); }
-            else { l = lane; x = item; }
-            tile[x * kPitch + l] = v[i];
+            for (int j = 0; j < 4; ++j) v[c][j] = base[(long long)ll + (long long)(c * kChunk + wave + 4 * j) * g.xstride];
         }
     }
-    SWEEP_STAMP(1);
-    __syncthreads();
-    SWEEP_STAMP(2);
 
-    // ---- sweeps: wave c < 3 handles channel c of line `lane`.  LDS reads run one batch of kBatch steps ahead of the
-    //      dependent chain (the chain is the critical path: a wave alone on its SIMD cannot hide LDS latency otherwise).
-    if (wave < 3 && lane < nvalid) {
-        const unsigned short* th = (const unsigned short*)tile + lane * 4;
-        unsigned short* tw = (unsigned short*)tile + lane * 4;
-        const int c = wave;
-        const float sky = c == 0 ? 1.0f : (c == 1 ? 1.2f : 2.0f);            // :24 SKYLIGHT
-        const float move_ratio = 0.5f;                                        // :33
-        constexpr int kBatch = 16, kBatches = kLen / kBatch;
-        // The shader's step for an empty voxel is  t = v + m;  m' = 0.5*t;  v' = t - m'.  Halving is exact in binary fp
-        // (no result here is near the fp32 subnormal range unless it is ~1e-30 below anything an fp16 store can see),
-        // so m' = fl(0.5*v + 0.5*m) = fmaf(0.5, m, 0.5*v) and v' = t - 0.5*t = m' bit for bit: the dependent chain is one
-        // FMA and one select per step, everything else is off the chain.  wv[x] holds 0.5 * (forward result of voxel x).
-        float wv[kLen];
-        unsigned cv[kBatch], ca[kBatch], nv[kBatch], na[kBatch];
-        float m = sky;                                                        // :36
+    if (t == 0) *(int*)(tile + kLen * kPitch) = 0;                            // backward-sweep progress counter (visible after the first barrier)
+    const bool sweeper = wave < 3 && lane < nvalid;
+    const unsigned short* th = (const unsigned short*)tile + lane * 4;
+    unsigned short* tw = (unsigned short*)tile + lane * 4;
+    const int ch = wave;                                                      // colour channel of this wave (waves 0-2)
+    const float sky = ch == 0 ? 1.0f : (ch == 1 ? 1.2f : 2.0f);               // :24 SKYLIGHT
+    const float move_ratio = 0.5f;                                            // :33
+    // The shader's step for an empty voxel is  t = v + m;  m' = 0.5*t;  v' = t - m'.  Halving is exact in binary fp
+    // (no result here is near the fp32 subnormal range unless it is ~1e-30 below anything an fp16 store can see),
+    // so m' = fl(0.5*v + 0.5*m) = fmaf(0.5, m, 0.5*v) and v' = t - 0.5*t = m' bit for bit: the dependent chain is one
+    // FMA and one select per step, everything else is off the chain.  wv[x] holds 0.5 * (forward result of voxel x).
+    float wv[kLen];
+    float m = sky;                                                            // :36
+
+    // ---- forward sweep, chunk by chunk as the data lands (:37-48)
 #pragma unroll
-        for (int j = 0; j < kBatch; ++j) { cv[j] = th[j * kPitch * 4 + c]; ca[j] = th[j * kPitch * 4 + 3]; }
+    for (int c = 0; c < kChunks; ++c) {
+        if (kContig) {
+            const int l = t >> 2, x = c * kChunk + (t & 3) * 4;
 #pragma unroll
-        for (int b = 0; b < kBatches; ++b) {                                  // :37-48
-            if (b + 1 < kBatches) {
+            for (int j = 0; j < 4; ++j) tile[(x + j) * kPitch + l] = v[c][j];
+        } else {
 #pragma unroll
-                for (int j = 0; j < kBatch; ++j) {
-                    int x = (b + 1) * kBatch + j;
-                    nv[j] = th[x * kPitch * 4 + c]; na[j] = th[x * kPitch * 4 + 3];
-                }
-            }
+            for (int j = 0; j < 4; ++j) tile[(c * kChunk + wave + 4 * j) * kPitch + lane] = v[c][j];
+        }
+        __syncthreads();
+        if (sweeper) {
+            unsigned cv[kChunk], ca[kChunk];
 #pragma unroll
-            for (int j = 0; j < kBatch; ++j) {
+            for (int j = 0; j < kChunk; ++j) { const int x = c * kChunk + j; cv[j] = th[x * kPitch * 4 + ch]; ca[j] = th[x * kPitch * 4 + 3]; }
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j) {
                 float ov = half_bits_to_float(cv[j]), a = half_bits_to_float(ca[j]);
                 float h = fmaf(move_ratio, m, move_ratio * ov);               // = 0.5 * (ov + m)
                 m = a > 0.5f ? ov : h;                                        // moving light, and the voxel's forward value
                 float w = move_ratio * m;
                 asm("" : "+v"(w));                                            // keep one value per step live, nothing else
-                wv[b * kBatch + j] = w;
+                wv[c * kChunk + j] = w;
             }
-#pragma unroll
-            for (int j = 0; j < kBatch; ++j) { cv[j] = nv[j]; ca[j] = na[j]; }
-        }
-        wv[kLen - 1] = m;                                                     // :49 values[127] += moving_light: (m + m) * 0.5
-        SWEEP_STAMP(3);
-        m = sky;                                                              // :52
-        const float keep = 1.0f - 0.35f;                                      // mix(x, y, a) = x*(1-a) + y*a
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            int x = kLen - 1 - j;
-            cv[j] = th[x * kPitch * 4 + c]; ca[j] = th[x * kPitch * 4 + 3];
-        }
-#pragma unroll
-        for (int b = 0; b < kBatches; ++b) {                                  // :53-66, fused with the store loop :70-75
-            if (b + 1 < kBatches) {
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j) {
-                    int x = kLen - 1 - ((b + 1) * kBatch + j);
-                    nv[j] = th[x * kPitch * 4 + c]; na[j] = th[x * kPitch * 4 + 3];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < kBatch; ++j) {
-                const int x = kLen - 1 - (b * kBatch + j);
-                unsigned ab = ca[j];
-                asm("" : "+v"(ab));                                           // opaque: re-test alpha rather than carry 128 lane masks
-                float ov = half_bits_to_float(cv[j]), a = half_bits_to_float(ab);
-                float h = fmaf(move_ratio, m, wv[x]);                         // = 0.5 * (forward value + m) = the voxel's new value
-                m = a > 0.5f ? ov : h;
-                float v = h;
-                if (x == 0) v = v + m;                                        // :67 (m is final here)
-                float mixed = ov * keep + v * 0.35f;
-                unsigned short nb = __half_as_ushort(__float2half_rn(mixed));
-                tw[x * kPitch * 4 + c] = a < 0.5f ? nb : (unsigned short)cv[j];   // :72 (other voxels keep their bits)
-            }
-#pragma unroll
-            for (int j = 0; j < kBatch; ++j) { cv[j] = nv[j]; ca[j] = na[j]; }
         }
     }
-    SWEEP_STAMP(4);
-    __syncthreads();
-    SWEEP_STAMP(5);
+    SWEEP_STAMP(3);
+    if (sweeper) wv[kLen - 1] = m;                                            // :49 values[127] += moving_light: (m + m) * 0.5
+    m = sky;                                                                  // :52
+    const float keep = 1.0f - 0.35f;                                          // mix(x, y, a) = x*(1-a) + y*a
 
-    // ---- write back the voxels the shader writes (:72 old alpha < 0.5; alpha itself is unchanged)
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) {
-        int item = wave + 4 * i, l, x;
-        if (g.contiguous_lines) { l = item >> 1; x = lane + 64 * (item & 1); }
-        else { l = lane; x = item; }
-        if (l < nvalid) {
-            uint2 v = tile[x * kPitch + l];
-            if (half_bits_to_float(v.y >> 16) < 0.5f) base[(long long)l * g.fstride + (long long)x * g.xstride] = v;
+    // ---- backward sweep (:53-66) fused with the mix (:70-75).  Waves 0-2 never wait: after each finished chunk they bump a
+    //      counter in LDS; wave 3 (no channel to sweep) polls it and streams every chunk all three have finished back to HBM
+    //      (:72 only voxels whose old alpha < 0.5; alpha itself is unchanged).  The counter reaches 3 * kChunks unconditionally,
+    //      so wave 3 always leaves its loop.
+    volatile int* progress = (volatile int*)(tile + kLen * kPitch);
+    if (wave < 3) {
+        unsigned cv[kChunk], ca[kChunk], nv[kChunk], na[kChunk];
+        if (sweeper) {
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j) { const int x = kLen - 1 - j; cv[j] = th[x * kPitch * 4 + ch]; ca[j] = th[x * kPitch * 4 + 3]; }
+        }
+#pragma unroll
+        for (int c = kChunks - 1; c >= 0; --c) {
+            if (sweeper) {
+                if (c > 0) {
+#pragma unroll
+                    for (int j = 0; j < kChunk; ++j) { const int x = c * kChunk - 1 - j; nv[j] = th[x * kPitch * 4 + ch]; na[j] = th[x * kPitch * 4 + 3]; }
+                }
+#pragma unroll
+                for (int j = 0; j < kChunk; ++j) {
+                    const int x = c * kChunk + kChunk - 1 - j;
+                    unsigned ab = ca[j];
+                    asm("" : "+v"(ab));                                       // opaque: re-test alpha rather than carry 128 lane masks
+                    float ov = half_bits_to_float(cv[j]), a = half_bits_to_float(ab);
+                    float h = fmaf(move_ratio, m, wv[x]);                     // = 0.5 * (forward value + m) = the voxel's new value
+                    m = a > 0.5f ? ov : h;
+                    float vv = h;
+                    if (x == 0) vv = vv + m;                                  // :67 (m is final here)
+                    float mixed = ov * keep + vv * 0.35f;
+                    unsigned short nb = __half_as_ushort(__float2half_rn(mixed));
+                    tw[x * kPitch * 4 + ch] = a < 0.5f ? nb : (unsigned short)cv[j];   // :72 (other voxels keep their bits)
+                }
+#pragma unroll
+                for (int j = 0; j < kChunk; ++j) { cv[j] = nv[j]; ca[j] = na[j]; }
+            }
+            // LDS operations of one wave complete in order: the counter bump lands after this chunk's tile writes
+            if (lane == 0) atomicAdd((int*)progress, 1);
+        }
+    } else {
+#pragma unroll 1
+        for (int done = kChunks - 1; done >= 0; --done) {
+            const int need = 3 * (kChunks - done);
+            while (*progress < need) __builtin_amdgcn_s_sleep(2);
+            if (g.pair_stores) {
+                // 16 B per lane.  Occupied voxels still hold their loaded bits in the tile, so storing a pair whole only rewrites
+                // identical data where the shader would have skipped the store (:72); this keeps wave 3 (the only storing
+                // wave) at 8 store instructions per chunk and ahead of the sweep.
+                if (kContig) {                                                // lane -> (8 lines x 8 voxel pairs)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int l = k * 8 + (lane >> 3), x = done * kChunk + 2 * (lane & 7);
+                        uint2 o0 = tile[x * kPitch + l], o1 = tile[(x + 1) * kPitch + l];
+                        if (l < nvalid) store_stream2(base + (long long)l * g.fstride + x, o0, o1);
+                    }
+                } else {                                                      // lane -> (line pair, step parity)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int l = 2 * (lane & 31), x = done * kChunk + 2 * k + (lane >> 5);
+                        uint2 o0 = tile[x * kPitch + l], o1 = tile[x * kPitch + l + 1];
+                        uint2* dst = base + (long long)l + (long long)x * g.xstride;
+                        if (l + 1 < nvalid) store_stream2(dst, o0, o1);
+                        else if (l < nvalid) store_stream(dst, o0);
+                    }
+                }
+            } else if (kContig) {                                             // lane -> (4 lines x 16 voxels): 128 B per line
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int l = k * 4 + (lane >> 4), x = done * kChunk + (lane & 15);
+                    uint2 o = tile[x * kPitch + l];
+                    if (l < nvalid && half_bits_to_float(o.y >> 16) < 0.5f) store_stream(base + (long long)l * g.fstride + x, o);
+                }
+            } else {                                                          // lane = line: 512-B rows
+#pragma unroll
+                for (int k = 0; k < kChunk; ++k) {
+                    const int x = done * kChunk + k;
+                    uint2 o = tile[x * kPitch + lane];
+                    if (lane < nvalid && half_bits_to_float(o.y >> 16) < 0.5f) store_stream(base + (long long)lane + (long long)x * g.xstride, o);
+                }
+            }
         }
     }
     SWEEP_STAMP(6);
@@ -201,12 +254,17 @@ extern "C" int pbrk_lightgrid_sweep(void* image_rgba16f, int w, int h, int d, in
         g.base = (long long)z0 * W + y0; g.nf = y1 - y0; ns = z1 - z0;
     }
     if (ns > 65535) return PBRK_E_ARG;
+    // 16-B stores need every even voxel of a tile row on a 16-B boundary: image base (hipMalloc: yes), offsets and strides even
+    g.pair_stores = ((uintptr_t)image_rgba16f % 16 == 0) && (g.base % 2 == 0) && (g.sstride % 2 == 0) &&
+                    (g.contiguous_lines ? (g.fstride % 2 == 0) : (g.xstride % 2 == 0));
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_lightgrid_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) != hipSuccess) return PBRK_E_LAUNCH;
+        if (hipFuncSetAttribute((const void*)k_lightgrid_sweep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) != hipSuccess) return PBRK_E_LAUNCH;
+        if (hipFuncSetAttribute((const void*)k_lightgrid_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) != hipSuccess) return PBRK_E_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_lightgrid_sweep, dim3((g.nf + kTile - 1) / kTile, ns), dim3(256), kLdsBytes, (hipStream_t)stream,
+    if (g.contiguous_lines) hipLaunchKernelGGL(k_lightgrid_sweep<true>, dim3((g.nf + kTile - 1) / kTile, ns), dim3(256), kLdsBytes, (hipStream_t)stream, (uint2*)image_rgba16f, g);
+    else hipLaunchKernelGGL(k_lightgrid_sweep<false>, dim3((g.nf + kTile - 1) / kTile, ns), dim3(256), kLdsBytes, (hipStream_t)stream,
                        (uint2*)image_rgba16f, g);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
