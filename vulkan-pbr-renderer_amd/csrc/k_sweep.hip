@@ -257,11 +257,13 @@ extern "C" int pbrk_lightgrid_sweep(void* image_rgba16f, int w, int h, int d, in
     // 16-B stores need every even voxel of a tile row on a 16-B boundary: image base (hipMalloc: yes), offsets and strides even
     g.pair_stores = ((uintptr_t)image_rgba16f % 16 == 0) && (g.base % 2 == 0) && (g.sstride % 2 == 0) &&
                     (g.contiguous_lines ? (g.fstride % 2 == 0) : (g.xstride % 2 == 0));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_device = -1;                                                // the attribute is per device
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return PBRK_E_LAUNCH;
+    if (attr_device != device) {
         if (hipFuncSetAttribute((const void*)k_lightgrid_sweep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) != hipSuccess) return PBRK_E_LAUNCH;
         if (hipFuncSetAttribute((const void*)k_lightgrid_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) != hipSuccess) return PBRK_E_LAUNCH;
-        attr_set = true;
+        attr_device = device;
     }
     if (g.contiguous_lines) hipLaunchKernelGGL(k_lightgrid_sweep<true>, dim3((g.nf + kTile - 1) / kTile, ns), dim3(256), kLdsBytes, (hipStream_t)stream, (uint2*)image_rgba16f, g);
     else hipLaunchKernelGGL(k_lightgrid_sweep<false>, dim3((g.nf + kTile - 1) / kTile, ns), dim3(256), kLdsBytes, (hipStream_t)stream,
