@@ -168,8 +168,11 @@ def synth_env(W, seed=0x5EED0001, rgbe_roundtrip=True, chunk_rows=256, workers=1
     jobs = [(W, seed, rgbe_roundtrip, f, chunk_rows) for f in range(6)]
     if workers > 1:
         import multiprocessing as mp
-        with mp.get_context("fork").Pool(min(6, workers)) as pool:
+        pool = mp.get_context("fork").Pool(min(6, workers))
+        try:
             faces = pool.map(_env_face, jobs)
+        finally:
+            pool.close(); pool.join()          # let workers exit on their own: Pool.terminate() signals them, which hangs under a preloaded profiler
     else:
         faces = [_env_face(j) for j in jobs]
     return np.stack(faces, axis=0)
@@ -372,8 +375,11 @@ def synth_gbuffer_temple(width=7680, height=4320, seed=0x5EED0005, cam_pos=(0.0,
     jobs = [(width, height, seed, tuple(cam_pos), ori_q, y0, min(r1, y0 + blk)) for y0 in range(r0, r1, blk)]
     if workers > 1 and len(jobs) > 1:
         import multiprocessing as mp
-        with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+        pool = mp.get_context("fork").Pool(min(workers, len(jobs)))
+        try:
             parts = pool.map(_temple_block, jobs)
+        finally:
+            pool.close(); pool.join()
     else:
         parts = [_temple_block(j) for j in jobs]
     for y0, y1, b, n, o_, e, d in parts:
