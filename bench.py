@@ -614,6 +614,9 @@ def post_bench(L, pbrhip, frames=20):
     lv = lambda w, h, m: max(1, w >> m) * max(1, h >> m)
     down_b = sum(8.0 * ((W * H if m == 0 else lv(W // 2, H // 2, m - 1)) + lv(W // 2, H // 2, m)) for m in range(6)) / 6
     up_b = sum(8.0 * (lv(W // 2, H // 2, 5) if m == 5 else lv(W, H, m + 1)) + 16.0 * lv(W, H, m) for m in range(6)) / 6
+    per_pass = lambda name: [float(np.mean(ms[name][k::6]) * 1e3) for k in range(6)]       # the six passes repeat frame after frame
+    res["bloom_downsample_us_by_pass"] = per_pass("K10.bloom_downsample")
+    res["bloom_upsample_us_by_pass"] = per_pass("K11.bloom_upsample")
     for name, byt in (("K8.taa_resolve", 36.0 * W * H), ("K10.bloom_downsample", down_b), ("K11.bloom_upsample", up_b), ("K9.final_post_process", 12.0 * W * H)):
         k_ms = float(np.mean(ms[name]))
         res["kernels"].append({"kernel": name, "avg_ms": k_ms, "bound": "hbm", "alg_bytes": byt,

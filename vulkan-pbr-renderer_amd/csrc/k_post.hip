@@ -305,7 +305,8 @@ __global__ __launch_bounds__(256) void k_final_post_process_stream(PbrkFinalArgs
 
 // K10 / K11: bloom passes.  Column / row tap coordinates repeat (5 distinct offsets for the 13-tap downsample, 3 for the
 // tent), so the snapped bilinear split is done once per distinct offset and the taps index the results.
-struct BloomParams { PbrkBloomArgs a; float x_step, y_step, rcp_dw, rcp_dh; };
+struct BloomParams { PbrkBloomArgs a; float x_step, y_step, rcp_dw, rcp_dh; int exact2to1; };
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 template <bool kUp>
 __global__ __launch_bounds__(256) void k_bloom_pass(BloomParams P) {
@@ -315,6 +316,83 @@ __global__ __launch_bounds__(256) void k_bloom_pass(BloomParams P) {
     if (px >= A.dst_width || py >= A.y1) return;
     const int SW = A.src.width, SH = A.src.height;
     const __amdgpu_buffer_rsrc_t rs = tex_rsrc(A.src, 8);
+    float r[3];
+    bool done = false;
+    // Exact 2:1 passes (every level of an even-sized chain; the two full-size passes of a 1080p frame): the snapped tap
+    // coordinates are known in closed form -- texel pairs at fraction 1/2 (down) or 1/4, 3/4 by pixel parity (up) -- so an
+    // interior pixel reads its 6x6 / 5x5 source window as whole rows (18 / 15 loads instead of 52 / 36) and needs no
+    // coordinate arithmetic.  Same lerps in the same order: bit-identical to the general path below (border pixels take it).
+    if (P.exact2to1) {
+        if (!kUp) {
+            if (px >= 1 && px <= A.dst_width - 2 && py >= 1 && py <= A.dst_height - 2) {
+                float hx[6][5][3];                                                      // rows x horizontal taps (offsets -2..2) x rgb
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr) {
+                    const int off = ((2 * py - 2 + rr) * SW + 2 * px - 2) * 8;
+                    u32x4v q0 = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0), q1 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 0);
+                    u32x4v q2 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 32, 0, 0);
+                    const unsigned w[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+                    float t[6][3];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) { t[c][0] = h2f(w[2 * c] & 0xffff); t[c][1] = h2f(w[2 * c] >> 16); t[c][2] = h2f(w[2 * c + 1] & 0xffff); }
+#pragma unroll
+                    for (int k = 0; k < 5; ++k)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) hx[rr][k][c] = lerpx(t[k][c], t[k + 1][c], 0.5f);
+                }
+                auto tapd = [&](int kx, int ky, int c) { return lerpx(hx[ky][kx][c], hx[ky + 1][kx][c], 0.5f); };
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float sum = tapd(2, 2, c) * 0.125f;
+                    sum = sum + (((tapd(0, 0, c) + tapd(4, 0, c)) + tapd(0, 4, c)) + tapd(4, 4, c)) * 0.03125f;
+                    sum = sum + (((tapd(2, 0, c) + tapd(0, 2, c)) + tapd(4, 2, c)) + tapd(2, 4, c)) * 0.0625f;
+                    sum = sum + (((tapd(1, 1, c) + tapd(3, 1, c)) + tapd(1, 3, c)) + tapd(3, 3, c)) * 0.125f;
+                    if (A.dst_mip_level == 1) sum = fminf(sum, 1.0f);
+                    r[c] = sum;
+                }
+                done = true;
+            }
+        } else {
+            const int i = px >> 1, j = py >> 1;
+            if (i >= 2 && i <= SW - 3 && j >= 2 && j <= SH - 3) {
+                const bool ox = px & 1, oy = py & 1;
+                const float fx_side = ox ? 0.75f : 0.25f, fx_mid = ox ? 0.25f : 0.75f;      // fractions of the taps at -1.5 / +1.5 and at 0
+                const float fy_side = oy ? 0.75f : 0.25f, fy_mid = oy ? 0.25f : 0.75f;
+                float hx[5][3][3];                                                      // rows x horizontal taps (left, centre, right) x rgb
+#pragma unroll
+                for (int rr = 0; rr < 5; ++rr) {
+                    const int off = ((j - 2 + rr) * SW + i - 2) * 8;
+                    u32x4v q0 = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0), q1 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 0);
+                    u32x2v q2 = __builtin_amdgcn_raw_buffer_load_b64(rs, off + 32, 0, 0);
+                    const unsigned w[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
+                    float t[5][3];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) { t[c][0] = h2f(w[2 * c] & 0xffff); t[c][1] = h2f(w[2 * c] >> 16); t[c][2] = h2f(w[2 * c + 1] & 0xffff); }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        hx[rr][0][c] = lerpx(t[0][c], t[1][c], fx_side);
+                        hx[rr][1][c] = lerpx(ox ? t[2][c] : t[1][c], ox ? t[3][c] : t[2][c], fx_mid);
+                        hx[rr][2][c] = lerpx(t[3][c], t[4][c], fx_side);
+                    }
+                }
+                auto tapu = [&](int kx, int ky, int c) {
+                    if (ky == 0) return lerpx(hx[0][kx][c], hx[1][kx][c], fy_side);
+                    if (ky == 2) return lerpx(hx[3][kx][c], hx[4][kx][c], fy_side);
+                    return lerpx(oy ? hx[2][kx][c] : hx[1][kx][c], oy ? hx[3][kx][c] : hx[2][kx][c], fy_mid);
+                };
+                const float factor = A.dst_mip_level == 0 ? 0.06f : 1.0f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float sum = tapu(1, 1, c) * 4.0f;
+                    sum = sum + (((tapu(1, 0, c) + tapu(0, 1, c)) + tapu(2, 1, c)) + tapu(1, 2, c)) * 2.0f;
+                    sum = sum + (((tapu(0, 0, c) + tapu(2, 0, c)) + tapu(0, 2, c)) + tapu(2, 2, c));
+                    r[c] = sum * factor / 16.0f;
+                }
+                done = true;
+            }
+        }
+    }
+    if (!done) {
     SharedRcp rw, rh;
     rw.d = (float)A.dst_width; rw.r = P.rcp_dw; rh.d = (float)A.dst_height; rh.r = P.rcp_dh;
     const float u = div_by((float)px + 0.5f, rw), v = div_by((float)py + 0.5f, rh);       // fs_uv (full-screen triangle)
@@ -333,7 +411,6 @@ __global__ __launch_bounds__(256) void k_bloom_pass(BloomParams P) {
         o[1] = lerpx(lerpx(t00.y, t10.y, ca[kx]), lerpx(t01.y, t11.y, ca[kx]), cb[ky]);
         o[2] = lerpx(lerpx(t00.z, t10.z, ca[kx]), lerpx(t01.z, t11.z, ca[kx]), cb[ky]);
     };
-    float r[3];
     if (kUp) {                                                                          // bloom_upsample.glsl:43-58
         float t[9][3];
 #pragma unroll
@@ -361,6 +438,7 @@ __global__ __launch_bounds__(256) void k_bloom_pass(BloomParams P) {
             r[c] = sum;
         }
     }
+    }   // general path
     uint2* o = (uint2*)A.dst + (size_t)py * A.dst_width + px;
     if (A.blend_additive) {
         Rgba d = unpack_rgba16f(*o);
@@ -423,6 +501,10 @@ extern "C" int pbrk_bloom_pass(const PbrkBloomArgs* a, void* stream) {
     p.x_step = (a->upsample ? 1.5f : 1.0f) / (float)a->src.width;                       // radius / size, 1 / size (the shaders' x, y)
     p.y_step = (a->upsample ? 1.5f : 1.0f) / (float)a->src.height;
     p.rcp_dw = 1.0f / (float)a->dst_width; p.rcp_dh = 1.0f / (float)a->dst_height;
+    // closed-form taps need the exact ratio and the snap to absorb the fp32 coordinate error (extents <= 8192), see the kernel
+    const bool small = a->src.width <= 8192 && a->src.height <= 8192 && a->dst_width <= 8192 && a->dst_height <= 8192;
+    p.exact2to1 = small && (a->upsample ? (a->dst_width == 2 * a->src.width && a->dst_height == 2 * a->src.height)
+                                        : (a->src.width == 2 * a->dst_width && a->src.height == 2 * a->dst_height));
     dim3 grid((a->dst_width + 63) / 64, (a->y1 - a->y0 + 3) / 4), block(256);
     if (a->upsample) hipLaunchKernelGGL((k_bloom_pass<true>), grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((k_bloom_pass<false>), grid, block, 0, (hipStream_t)stream, p);
