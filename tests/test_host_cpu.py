@@ -280,3 +280,19 @@ def test_hdr_codec_under_sanitizers(tmp_path):
     assert b.returncode == 0, b.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("ok:"), (r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_public_headers_are_self_contained(tmp_path):
+    """Every header under include/ compiles on its own as C11 (pedantic) and as C++17: what a reference-side build would include."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc") or not shutil.which("g++"):
+        pytest.skip("no host compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "include")
+    for h in sorted(os.listdir(inc)):
+        for cc, std, ext in (("gcc", "-std=c11", ".c"), ("g++", "-std=c++17", ".cpp")):
+            src = tmp_path / ("t" + ext)
+            src.write_text(f'#include "{h}"\nint main(void) {{ return 0; }}\n')
+            r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I" + inc, str(src)], capture_output=True, text=True)
+            assert r.returncode == 0, (h, cc, r.stderr[-1500:])
