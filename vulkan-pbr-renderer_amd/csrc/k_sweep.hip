@@ -16,8 +16,10 @@
 //   * waves 0..2 each sweep one colour channel of the 64 lines (lane = line); the forward pass keeps its 128
 //     results in VGPRs (fully unrolled), the backward pass finishes each voxel and writes the mixed fp16
 //     value into the tile; the alpha channel is left as loaded (mix(a, a, .35) rounds back to a in fp16);
-//   * the write-back stores exactly the voxels the shader stores (old alpha < 0.5).
-// HBM traffic: 8 B read per voxel + 8 B written per empty voxel; 128^3 -> 16 MiB + <= 16 MiB.
+//   * the kernel is streamed (see k_lightgrid_sweep): loads are released chunk by chunk to the forward sweep, and wave 3 -- which
+//     has no channel -- streams chunks the backward sweep has finished back to HBM; occupied voxels keep their loaded bits,
+//     so whole-pair stores rewrite identical data where the shader skips the store (old alpha >= 0.5).
+// HBM traffic: 8 B read + 8 B written per voxel; 128^3 -> 32 MiB.
 #include "pbr_device.h"
 #include "pbr_kernels.h"
 
@@ -46,8 +48,7 @@ __device__ unsigned long long* g_sweep_prof;
 #define SWEEP_STAMP(k) do {} while (0)
 #endif
 
-// streaming store: the swept voxels are not read again by this kernel, and a write-back L2 would otherwise hold all 16 MiB
-// until the end-of-kernel release flushes them in one exposed burst
+// streaming (non-temporal) store: the swept voxels are not read again by this kernel
 __device__ __forceinline__ void store_stream(uint2* p, uint2 v) {
     __builtin_nontemporal_store(((unsigned long long)v.y << 32) | v.x, (unsigned long long*)p);
 }
