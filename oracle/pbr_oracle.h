@@ -6,11 +6,14 @@
  * pbr_oracle.c).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * call into this library; the product (libgpu_hip.so) never links or loads it.
  *
- * Pinning: the Monte-Carlo maths is pinned by known-answer vectors obtained by executing the
- * reference's own shader text on the CPU (tests/golden/oracle_a_*.json|npy, generator
- * oracle/gen_oracle_a.py, values also listed in SURVEY.md 8c).  Texture filtering
- * (seamless-cube bilinear, 2:1 blit) is implementation-defined in Vulkan and the reference
- * has no tests: that part is "parity unpinned" and fixed by the definitions in pbr_oracle.c.
+ * Pinning: all shader arithmetic -- the Monte-Carlo maths, the lighting pass including its sun-shadow, light-shaft and
+ * voxel-GI blocks, the light-grid sweep, TAA resolve, bloom and tone-map passes -- is pinned by known-answer vectors obtained
+ * by executing the reference's own shader text on the CPU (tests/golden/oracle_a_*.json|npy|npz, generator
+ * oracle/gen_oracle_a.py, values also listed in SURVEY.md 8c); this library reproduces every one of them bit for bit.
+ * What the reference delegates to the Vulkan driver and never tests is "parity unpinned" and fixed by the definitions in
+ * pbr_oracle.c: texture filtering (seamless-cube bilinear, 2:1 blit, the 2-D / 3-D / shadow samplers with their 1/256
+ * coordinate snap), render-target rounding (fp16 RTE, unorm8 RTE), additive blending at fp16, and the precision of
+ * sin / cos / acos (fixed fp32 polynomials for the per-pixel trig of the GI block; libm for the host-side sample tables).
  */
 #ifndef PBR_ORACLE_H
 #define PBR_ORACLE_H
@@ -42,7 +45,7 @@ typedef struct OrcGlobals {
 
 enum {
     ORC_SHADE_IBL       = 1 << 0, /* ambient = irradiance(N), spec = prefiltered(R, rough*4) (lighting_pass.glsl:690,699) */
-    ORC_SHADE_SHAFTS    = 1 << 1, /* light-shaft loop with visibility == 1 (lighting_pass.glsl:622-651) */
+    ORC_SHADE_SHAFTS    = 1 << 1, /* light-shaft loop (lighting_pass.glsl:622-651); visibility == 1 unless ORC_SHADE_SHADOWS */
     ORC_SHADE_ANALYTIC  = 1 << 2, /* analytic stand-ins for the env/irradiance/prefiltered/LUT textures */
     ORC_SHADE_SHADOWS   = 1 << 3, /* sun shadow PCF (:594-608) and light-shaft visibility (:646) from sun_depth_map */
     ORC_SHADE_GI        = 1 << 4  /* the live ambient / specular terms: SampleRadianceWithScreenSpaceTrace (:273-424, :685, :701) */

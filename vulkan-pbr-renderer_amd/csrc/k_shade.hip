@@ -6,9 +6,11 @@
 // position reconstruction :444-451, interleaved-gradient noise :456-459, view vector :612-613,
 // F0/kS/kD :657-661, sun term (GGX D :21-31, Mikkelsen G :72-74, Schlick F :76-79) :664-679,
 // split-sum LUT fetch :681, reflection vector :693-697, specular compose :702, emissive :706,
-// sky :708-710, clamp :712-713.  IBL mode adds the commented lines :690 and :699.  The voxel-GI /
-// shadow-map / screen-space blocks are out of scope (GI == 0, shadow == 1); light shafts (:622-651)
-// are available with visibility == 1.
+// sky :708-710, clamp :712-713.  IBL mode adds the commented lines :690 and :699.  The blocks fed by
+// raster passes are optional (flags): sun shadows :594-608 and light shafts :622-651 (PBRK_SHADE_SHADOWS /
+// _SHAFTS, sun depth map), the voxel-GI ambient / specular traces :273-424, :546-577, :685, :701
+// (PBRK_SHADE_GI, instantiation k_shade<true>: light grid, previous-frame pyramid, depth buffer).  With all
+// three the kernel is the reference's complete live shader; without them GI == 0 and shadow == 1.
 //
 // Streaming kernel: 20 B read + 8 B written per pixel; irradiance / prefiltered cubes, LUT and
 // Globals are cache resident.  Discontinuous inputs (noise, sky test, N.L > 0) are evaluated in the
