@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void k_taa_resolve(PbrkTaaArgs A) {
             wsum = wsum + w;
             if (depth < closest_depth) { closest_depth = depth; cdu = su; cdv = sv; }   // :222-225: only the first tap (-1,-1) can win
         }
-    float src[3] = {tot[0] / wsum, tot[1] / wsum, tot[2] / wsum};               // :228
+    const SharedRcp rws = shared_rcp(wsum);                                      // one reciprocal, three exact quotients (pbr_device.h)
+    float src[3] = {div_by(tot[0], rws), div_by(tot[1], rws), div_by(tot[2], rws)};   // :228
     float2 vel;
     if (kCentreExact && closest_depth < 10000.0f) vel = fetch_rg16f(rs_v, W, clampi(px - 1, 0, W - 1), clampi(py - 1, 0, H - 1));
     else vel = sample_rg16f(A.gbuffer_velocity, cdu, cdv);                      // :230
@@ -227,6 +228,8 @@ __global__ __launch_bounds__(256) void k_taa_resolve(PbrkTaaArgs A) {
     wB = wB + 1000.0f * sqrtf(dvx * dvx + dvy * dvy);                           // :269-270
     if (ru != fminf(fmaxf(ru, 0.0f), 1.0f) || rv != fminf(fmaxf(rv, 0.0f), 1.0f)) { wA = 0.0f; wB = 1.0f; }   // :272-275
     const float den = fmaxf(wB + wA, 0.00001f);
+    // true divisions: `den` is data (a shared-reciprocal quotient would be 1 ulp off whenever its significand is all ones:
+    // a handful of pixels per 1080p frame, and this kernel is bit-exact)
     float r0 = (src[0] * wB + prev[0] * wA) / den, r1 = (src[1] * wB + prev[1] * wA) / den, r2 = (src[2] * wB + prev[2] * wA) / den;   // :277
     const size_t o = (size_t)py * A.width + px;
     if (kHalfOut) ((uint2*)A.out)[o] = pack_half4(r0, r1, r2);

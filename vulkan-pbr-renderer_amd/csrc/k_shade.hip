@@ -115,11 +115,12 @@ __device__ __forceinline__ f3 level_fetch(const float4* __restrict__ pyr, const 
     return fetch_rgb_tap(pyr + tab[l], n, tp);
 }
 // trilinear fetch from a bordered pyramid (sampler: linear mip filter, LOD clamped to the chain)
+template <bool kExactDiv>
 __device__ __forceinline__ f3 pyramid_fetch(const float4* __restrict__ pyr, const float4* __restrict__ cells, int cells_first,
                                             int W, int levels, f3 d, float lod, const int* tab) {
     CubeST cs = cube_select(d);
     float s, t;
-    cube_st_exact(cs, &s, &t);
+    if (kExactDiv) cube_st_exact(cs, &s, &t); else cube_st_shared(cs, &s, &t);
     float maxl = (float)(levels - 1);
     lod = fminf(fmaxf(lod, 0.0f), maxl);
     float fl = floorf(lod);
@@ -344,8 +345,11 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
         float fs_u = div_by((float)px + 0.5f, rw), fs_v = div_by((float)py + 0.5f, rh);
         float pw[4];
         mat_mul(p.wfc, fs_u * 2.0f - 1.0f, fs_v * 2.0f - 1.0f, depth, 1.0f, pw);   // world_space_from_clip
-        SharedRcp rpw = shared_rcp(pw[3]);
-        f3 P = mk3(div_by(pw[0], rpw), div_by(pw[1], rpw), div_by(pw[2], rpw));
+        // kGI: the traces branch on quantities derived from P, V, R: true divisions there, so that the kernel follows the CPU
+        // evaluation always; the other modes (1e-4 tolerance, no data-dependent control flow) share reciprocals
+        f3 P;
+        if (kGI) P = mk3(pw[0] / pw[3], pw[1] / pw[3], pw[2] / pw[3]);
+        else { SharedRcp rpw = shared_rcp(pw[3]); P = mk3(div_by(pw[0], rpw), div_by(pw[1], rpw), div_by(pw[2], rpw)); }
 
         // :456-459
         float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
             shadow = acc * 0.25f;
         }
         f3 cam = mk3(p.cam[0], p.cam[1], p.cam[2]);
-        f3 V = normalize3(sub3(cam, P));                                               // :612
+        f3 V = kGI ? normalize3(sub3(cam, P)) : normalize3_shared(sub3(cam, P));       // :612
         float VdotN = fmaxf(dot3(V, N), 0.0f);                                         // :613
         f3 sun_emission = mk3(25.0f * 1.0f, 25.0f * 0.9f, 25.0f * 0.7f);               // :616
         f3 outl = mk3(0.0f, 0.0f, 0.0f);
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
 
         // :708-710 the sky branch replaces everything else: take it first (most waves of a frame are all-sky or all-surface)
         if (sky) {
-            outl = pyramid_fetch(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, mk3(-V.x, -V.y, -V.z), 1.0f, level_tab);
+            outl = pyramid_fetch<kGI>(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, mk3(-V.x, -V.y, -V.z), 1.0f, level_tab);
         } else {
             if (p.flags & PBRK_SHADE_SHAFTS) {                                   // :622-651
                 float cp4[4];
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
             {
                 f3 L = mk3(-p.sun[0], -p.sun[1], -p.sun[2]);
                 f3 Hs = add3(L, V);
-                f3 H = normalize3(Hs);        // exact: the GGX lobe amplifies an error in N.H by 1/a^2 (1300x at roughness 1/6)
+                f3 H = kGI ? normalize3(Hs) : normalize3_shared(Hs);   // no rsq here: the GGX lobe amplifies an error in N.H by 1/a^2 (1300x at roughness 1/6)
                 float NdotL = fmaxf(dot3(N, L), 0.0f);
                 if (NdotL > 0.0f) {
                     float VdotH = fmaxf(dot3(V, H), 0.0f);
@@ -447,7 +451,10 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
                 float2 sb = lut_fetch(p.lut, p.lut_cells, p.lut_size, VdotN, fmaxf(roughness, 0.05f));  // :681
                 f3 ambient = mk3(0.0f, 0.0f, 0.0f);
                 if (p.flags & PBRK_SHADE_IBL) {                                            // :690 (commented line)
-                    CubeTap tp = cube_tap<true>(N, p.irr_size);
+                    CubeST cs = cube_select(N);
+                    float si, ti;
+                    if (kGI) cube_st_exact(cs, &si, &ti); else cube_st_shared(cs, &si, &ti);
+                    CubeTap tp = cube_tap_from_st(cs.face, si, ti, p.irr_size);
                     ambient = p.irr_cells ? fetch_rgb_cells_tap(p.irr_cells, p.irr_size, tp) : fetch_rgb_tap(p.irr, p.irr_size, tp);
                 }
                 float p0_view[4] = {0.0f, 0.0f, 0.0f, 1.0f};
@@ -476,12 +483,13 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
                 float dNI = dot3(N, I);
                 f3 R = mk3(I.x - 2.0f * dNI * N.x, I.y - 2.0f * dNI * N.y, I.z - 2.0f * dNI * N.z);
                 float jr = 0.6f * roughness;
-                R = normalize3(mk3(R.x + jr * (noise_1 - 0.5f), R.y + jr * (noise_2 - 0.5f), R.z + jr * (noise_3 - 0.5f)));
+                f3 Rj = mk3(R.x + jr * (noise_1 - 0.5f), R.y + jr * (noise_2 - 0.5f), R.z + jr * (noise_3 - 0.5f));
+                R = kGI ? normalize3(Rj) : normalize3_shared(Rj);
                 float r2 = roughness * roughness;
                 float r4 = r2 * r2;
                 R = mk3(mix_(R.x, N.x, r4), mix_(R.y, N.y, r4), mix_(R.z, N.z, r4));
                 f3 spec = mk3(0.0f, 0.0f, 0.0f);
-                if (p.flags & PBRK_SHADE_IBL) spec = pyramid_fetch(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, R, roughness * 4.0f, level_tab);   // :699
+                if (p.flags & PBRK_SHADE_IBL) spec = pyramid_fetch<kGI>(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, R, roughness * 4.0f, level_tab);   // :699
                 if (gi) spec = sample_radiance_ss(p, V, p0_view, P, R, 16, 2.0f, noise_3, roughness, 0.9f);   // :701
                 outl.x += spec.x * (F0.x * sb.x + sb.y);                                   // :702
                 outl.y += spec.y * (F0.y * sb.x + sb.y);

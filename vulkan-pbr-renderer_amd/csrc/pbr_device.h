@@ -34,8 +34,15 @@ __device__ __forceinline__ float div_by(float a, const SharedRcp& e) {
     float rem = fmaf(-q, e.d, a);
     return fmaf(rem, e.r, q);
 }
+// EXACT: a / length(a) with three true divisions (bit-identical to a scalar CPU evaluation, always)
 __device__ __forceinline__ f3 normalize3(f3 a) {
-    SharedRcp e = shared_rcp(sqrtf(dot3(a, a)));   // sqrtf: correctly rounded expansion (unlike __fsqrt_rn, which is the 1-ulp v_sqrt_f32)
+    float len = sqrtf(dot3(a, a));   // correctly rounded expansion (unlike __fsqrt_rn, which is the 1-ulp v_sqrt_f32)
+    return mk3(__fdiv_rn(a.x, len), __fdiv_rn(a.y, len), __fdiv_rn(a.z, len));
+}
+// the same through one shared reciprocal: ~half the instructions, identical except when len's significand is all ones
+// (2^-23 of the inputs, then 1 ulp) -- for the shade pass at 1e-4, not for lookups that must match bit for bit
+__device__ __forceinline__ f3 normalize3_shared(f3 a) {
+    SharedRcp e = shared_rcp(sqrtf(dot3(a, a)));
     return mk3(div_by(a.x, e), div_by(a.y, e), div_by(a.z, e));
 }
 
@@ -99,6 +106,10 @@ __device__ __forceinline__ CubeST cube_select(f3 d) {
 }
 // EXACT sampler coordinates s,t in [0,1] (independent of the level): s = (0.5*sc)/|rc| + 0.5
 __device__ __forceinline__ void cube_st_exact(const CubeST& c, float* s, float* t) {
+    *s = 0.5f * c.sc / c.ma + 0.5f;
+    *t = 0.5f * c.tc / c.ma + 0.5f;
+}
+__device__ __forceinline__ void cube_st_shared(const CubeST& c, float* s, float* t) {     // see normalize3_shared
     SharedRcp rma = shared_rcp(c.ma);
     *s = div_by(0.5f * c.sc, rma) + 0.5f;
     *t = div_by(0.5f * c.tc, rma) + 0.5f;
