@@ -193,6 +193,12 @@ typedef struct PbrkBloomArgs {
 } PbrkBloomArgs;
 int pbrk_bloom_pass(const PbrkBloomArgs* args, void* stream);
 
+/* ---- diagnostics: the device samplers of the widened passes evaluated at caller-supplied coordinates, so that tests can feed them
+ *      NaN / inf / 1e30 / boundary values directly (a ray that has marched far away must never become an out-of-bounds read).
+ *      which: 0 = LIGHTGRID (RGBA16F n^3, coords xyz), 1 = sampler2DShadow (R32F w x h, coords u, v, ref; result in out[0]),
+ *      2 = the post-process 2-D sampler (RGBA16F w x h, coords u, v).  coords: device float[count][3]; out: device float[count][4]. */
+int pbrk_debug_sample(int which, const void* texture, int w, int h, int d, const void* coords, int count, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

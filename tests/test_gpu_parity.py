@@ -380,3 +380,50 @@ def test_shade_complete_live_shader_vs_oracle(gpu, size):
     L.GPU_DestroyGraph(g); L.PBR_DestroyLightingPass(lp); L.PBR_DestroyGBuffer(C.byref(gb)); L.PBR_DestroyIBLMaps(C.byref(maps))
     for t in (env_tex, grid_tex, prev_tex, sun_tex):
         L.GPU_DestroyTexture(t)
+
+
+def test_device_samplers_at_wild_coordinates(gpu):
+    """The 3-D / shadow / post-process samplers at NaN, +-inf, +-1e30, -0.0, exact texel centres and edges: no out-of-bounds read (a
+    marching ray can reach such coordinates; an earlier version converted them to int unclamped and faulted) and, wherever the
+    result is defined, the same bits as the oracle."""
+    import pbrhip, pbr_oracle as O
+    L = gpu
+    rng = np.random.default_rng(0xC00D)
+    special = np.array([0.0, -0.0, 1.0, 0.5, 0.25, 1e-30, -1e-30, 1e30, -1e30, np.inf, -np.inf, np.nan, 3.0e9, -3.0e9, 2.0 ** 31, 1.0 - 2.0 ** -24], np.float32)
+    coords = np.concatenate([rng.uniform(-0.5, 1.5, (4096, 3)), rng.choice(special, (4096, 3)),
+                             np.stack([(np.arange(64) + 0.5) / 64] * 3, -1)]).astype(np.float32)
+    n = len(coords)
+    cbuf = L.GPU_MakeBuffer(coords.nbytes, pbrhip.BufferFlag_CPU, coords.ctypes.data_as(C.c_void_p))
+    obuf = L.GPU_MakeBuffer(n * 16, pbrhip.BufferFlag_CPU, None)
+
+    def run(which, tex, w, h, d):
+        assert L.pbrk_debug_sample(which, L.GPUX_TextureDevicePtr(tex, 0), w, h, d, L.GPUX_BufferDevicePtr(cbuf), n, L.GPUX_BufferDevicePtr(obuf), None) == 0
+        L.GPU_WaitUntilIdle()
+        return np.frombuffer((C.c_char * (n * 16)).from_address(obuf.contents.data), np.float32).reshape(n, 4).copy()
+
+    grid = (rng.random((16, 16, 16, 4)) * 4).astype(np.float16)
+    gtex = pbrhip.make_texture(pbrhip.Format_RGBA16F, 16, 16, pbrhip.TextureFlag_StorageImage, depth=16)
+    pbrhip.upload_mip(gtex, 0, grid)
+    got = run(0, gtex, 16, 16, 16)
+    want = np.zeros_like(got)
+    g16 = np.ascontiguousarray(grid.view(np.uint16))
+    for i in range(n):
+        p = np.ascontiguousarray(coords[i])
+        O.lib().orc_tex3d_sample(g16.ctypes.data_as(C.c_void_p), 16, p.ctypes.data_as(C.c_void_p), want[i].ctypes.data_as(C.c_void_p))
+    assert np.array_equal(got, want, equal_nan=True)
+    depth = rng.random((24, 40)).astype(np.float32)
+    dtex = pbrhip.make_texture(pbrhip.Format_D32F_Or_X8D24UN, 40, 24, pbrhip.TextureFlag_RenderTarget)
+    pbrhip.upload_mip(dtex, 0, depth)
+    got = run(1, dtex, 40, 24, 1)[:, 0]
+    t = O._tex2d(depth, O.TEX_R32F)[0]
+    want = np.array([O.lib().orc_shadow_sample(t, float(c[0]), float(c[1]), float(c[2])) for c in coords], np.float32)
+    assert np.array_equal(got, want, equal_nan=True)
+    img = (rng.random((24, 40, 4)) * 4).astype(np.float16)
+    itex = pbrhip.make_texture(pbrhip.Format_RGBA16F, 40, 24, pbrhip.TextureFlag_RenderTarget)
+    pbrhip.upload_mip(itex, 0, img)
+    got = run(2, itex, 40, 24, 1)
+    want = np.stack([O.tex2d_sample(img, O.TEX_RGBA16F, float(c[0]), float(c[1])) for c in coords])
+    assert np.array_equal(got, want, equal_nan=True)
+    for t_ in (gtex, dtex, itex):
+        L.GPU_DestroyTexture(t_)
+    L.GPU_DestroyBuffer(cbuf); L.GPU_DestroyBuffer(obuf)

@@ -450,6 +450,13 @@ __global__ __launch_bounds__(256) void k_bloom_pass(BloomParams P) {
     *o = pack_half4(r[0], r[1], r[2]);
 }
 
+__global__ void k_debug_sample_post(PbrkTex2D t, const float* __restrict__ coords, int count, float4* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Rgba r = sample_rgba16f(t, coords[i * 3], coords[i * 3 + 1]);
+    out[i] = make_float4(r.x, r.y, r.z, r.w);
+}
+
 bool tex_ok(const PbrkTex2D& t, int fmt) { return t.data && t.format == fmt && t.width > 0 && t.height > 0; }
 }  // namespace
 
@@ -511,5 +518,11 @@ extern "C" int pbrk_bloom_pass(const PbrkBloomArgs* a, void* stream) {
     dim3 grid((a->dst_width + 63) / 64, (a->y1 - a->y0 + 3) / 4), block(256);
     if (a->upsample) hipLaunchKernelGGL((k_bloom_pass<true>), grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((k_bloom_pass<false>), grid, block, 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int pbrk_debug_sample_post(const void* texture, int w, int h, const void* coords, int count, void* out, void* stream) {
+    PbrkTex2D t; t.data = texture; t.format = PBRK_FMT_RGBA16F; t.width = w; t.height = h;
+    hipLaunchKernelGGL(k_debug_sample_post, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, (const float*)coords, count, (float4*)out);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }

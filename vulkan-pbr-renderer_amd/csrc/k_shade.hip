@@ -18,6 +18,7 @@
 #include "pbr_device.h"
 #include "pbr_kernels.h"
 #include <hip/hip_fp16.h>
+#include <string.h>
 
 struct ShadeParams {
     int width, height, x0, y0, w, h;
@@ -527,6 +528,27 @@ extern "C" int pbrk_lut_cells_build(const void* lut_half2, int size, void* cells
     if (!lut_half2 || !cells_out || size < 1) return PBRK_E_ARG;
     int total = (size + 1) * (size + 1);
     hipLaunchKernelGGL(k_lut_cells, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const unsigned*)lut_half2, (uint4*)cells_out, size);
+    return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+}
+
+// diagnostics (pbrk_debug_sample): the samplers above at arbitrary coordinates
+__global__ void k_debug_sample_shade(int which, ShadeParams p, const float* __restrict__ coords, int count, float4* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float a = coords[i * 3], b = coords[i * 3 + 1], c = coords[i * 3 + 2];
+    if (which == 0) out[i] = grid_sample(p, a, b, c);
+    else out[i] = make_float4(shadow_sample(p.sun_depth, p.sun_w, p.sun_h, a, b, c), 0.0f, 0.0f, 0.0f);
+}
+extern "C" __attribute__((visibility("hidden"))) int pbrk_debug_sample_post(const void* texture, int w, int h, const void* coords, int count, void* out, void* stream);
+extern "C" int pbrk_debug_sample(int which, const void* texture, int w, int h, int d, const void* coords, int count, void* out, void* stream) {
+    if (!texture || !coords || !out || count < 1 || w < 1 || h < 1 || d < 1 || which < 0 || which > 2) return PBRK_E_ARG;
+    if (which == 2) return pbrk_debug_sample_post(texture, w, h, coords, count, out, stream);
+    if (which == 0 && !(w == h && h == d && w <= 1024)) return PBRK_E_ARG;
+    ShadeParams p;
+    memset(&p, 0, sizeof p);
+    p.grid = (const uint2*)texture; p.grid_n = w;
+    p.sun_depth = (const float*)texture; p.sun_w = w; p.sun_h = h;
+    hipLaunchKernelGGL(k_debug_sample_shade, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, which, p, (const float*)coords, count, (float4*)out);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
 
