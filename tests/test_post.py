@@ -287,3 +287,36 @@ def test_gpu_bloom_full_frame_and_errors(gpu):
     finally:
         L.GPUX_SetErrorHandler(None, None)
     L.PBR_DestroyPostProcess(pp); L.PBR_DestroyGBuffer(C.byref(gb))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W", [7680, 8192, 8200])
+def test_gpu_post_wide_frames(gpu, W):
+    """Widths at the edge of the closed-form tap assumption (the 1/256 snap must absorb the fp32 coordinate error: 7680 = the 8K frame,
+    8192 = the limit) and just beyond it, where K8 / K9 / K10 / K11 switch to their general paths (every tap through the snapped
+    bilinear sampler): same bits as the oracle on W x 12 frames."""
+    import pbrhip
+    from pbrhip.synth import synth_post_inputs
+    L = gpu
+    H = 12
+    lighting, depth, vel, vel_prev, history = synth_post_inputs(0x5EED00DA, W, H)
+    vel[:, :512] = vel_prev[:, :512] = 0                           # keep the left strip on-screen so that history is sampled there
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), W, H, pbrhip.Format_RGBA16F)
+    pp = L.PBR_MakePostProcess(C.byref(gb), W, H, pbrhip.Format_RGBA8UN)
+    _upload(gb.lighting_result, lighting); _upload(gb.depth, depth)
+    _upload(L.PBR_PostVelocity(pp, 0), vel); _upload(L.PBR_PostVelocity(pp, 1), vel_prev)
+    _upload(L.PBR_PostTaaOutput(pp, 1), history)
+    g = L.GPU_MakeGraph()
+    L.PBR_RecordTaaResolve(pp, g, 0); L.PBR_RecordBloom(pp, g, 0); L.PBR_RecordFinalPostProcessBloom(pp, g, 0)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g); L.GPU_DestroyGraph(g)
+    taa = pbrhip.read_mip(L.PBR_PostTaaOutput(pp, 0), 0)
+    want = O.taa_resolve(lighting, depth, vel, vel_prev, history).astype(np.float16)
+    assert np.array_equal(taa.view(np.uint16), want.view(np.uint16))
+    n = L.PBR_PostBloomPassCount(pp)
+    down, up = O.bloom_chain(taa, n)
+    _check_bloom(L, pbrhip, pp, down, up)
+    bb = pbrhip.read_mip(L.PBR_PostBackbuffer(pp), 0)
+    want8 = O.unorm8(O.final_post_process(up[0]))
+    assert np.abs(bb.astype(np.int32) - want8.astype(np.int32)).max() <= 1
+    L.PBR_DestroyPostProcess(pp); L.PBR_DestroyGBuffer(C.byref(gb))
