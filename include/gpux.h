@@ -71,4 +71,10 @@ GPU_API uint32_t GPUX_GraphTimedOpCount(GPU_Graph* graph);          /* ops of th
 GPU_API const char* GPUX_GraphTimedOpName(GPU_Graph* graph, uint32_t index);
 GPU_API float GPUX_GraphTimedOpMs(GPU_Graph* graph, uint32_t index);
 
+/* ---- overlap of small precompute dispatches: consecutive row-ranged K3/K4 dispatches (GPUX_OpDispatchRows) of fewer than
+ * 2M texels whose outputs are disjoint and that do not read each other's output are spread over `count` side streams
+ * between a fork and a join event; anything else executes in recording order on the graph's stream.  0 or 1 turns it off,
+ * a negative count restores the default (environment PBR_TILE_STREAMS, else 4).  Results do not depend on the setting. ---- */
+GPU_API void GPUX_SetTileStreams(int count);
+
 #endif

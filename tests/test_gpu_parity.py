@@ -236,6 +236,35 @@ def test_sharded_units_equal_full_dispatch(gpu, env64):
     L.PBR_DestroyIBLMaps(C.byref(maps)); L.GPU_DestroyTexture(full); L.GPU_DestroyTexture(irr_full)
 
 
+def test_tile_streams_keep_order_between_dependent_dispatches(gpu, env64):
+    """Small independent tile dispatches overlap on side streams (GPUX_SetTileStreams); a dispatch that samples what an earlier
+    one in the same graph wrote must still see it.  Chain env -> A -> B recorded in one graph: bit-identical with 0, 3, 4 streams."""
+    import pbrhip
+    env, tex = env64
+    L = gpu
+    results = []
+    for streams in (0, 4, 3, -1):
+        L.GPUX_SetTileStreams(streams)
+        a = pbrhip.PBR_IBLMaps(); b = pbrhip.PBR_IBLMaps()
+        L.PBR_MakeIBLMaps(C.byref(a), 32, 64, 64)
+        L.PBR_MakeIBLMaps(C.byref(b), 16, 64, 32)
+        pipes = L.PBR_MakeIBLPipelines(); arena = L.GPU_MakeDescriptorArena(); g = L.GPU_MakeGraph()
+        for rank in range(3):
+            units, n = pbrhip.partition(64, 1, 32, 64, 3, rank)
+            L.PBR_RecordUnits(pipes, g, arena, tex, C.byref(a), units, n)
+        for rank in range(2):                                  # second stage samples the map the first stage is still writing
+            units, n = pbrhip.partition(32, 1, 16, 64, 2, rank)
+            L.PBR_RecordUnits(pipes, g, arena, a.tex_specular_env_map, C.byref(b), units, n)
+        L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+        results.append([pbrhip.read_mip(b.tex_specular_env_map, m).copy() for m in range(6)] + [pbrhip.read_mip(b.irradiance_map, 0).copy()])
+        L.GPU_DestroyGraph(g); L.GPU_DestroyDescriptorArena(arena); L.PBR_DestroyIBLPipelines(pipes)
+        L.PBR_DestroyIBLMaps(C.byref(a)); L.PBR_DestroyIBLMaps(C.byref(b))
+    assert float(np.abs(results[0][1]).max()) > 0.0
+    for r in results[1:]:
+        for x, y in zip(results[0], r):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+
+
 def test_shade_random_bytes_all_decodes(gpu):
     """Every unorm8 value in every channel (exact b/255 decode), non-unit normals, random depths incl. sky."""
     import pbrhip, pbr_oracle as O

@@ -108,6 +108,10 @@ struct Op {
 struct DrawParams { GPU_GraphicsPipeline* pipeline; GPU_DescriptorSet* set; };
 struct GPU_Graph {
     hipStream_t stream = nullptr;
+    hipStream_t cur = nullptr;                     // stream the op being executed launches on (stream, or a side stream)
+    std::vector<hipStream_t> side;                 // side streams for overlapping independent tile dispatches (created on first use)
+    std::vector<hipEvent_t> sync_ev;               // untimed fork/join events
+    size_t sync_used = 0;
     std::vector<Op> ops;
     bool submitted = false;
     GPU_ComputePipeline* bound_cpipe = nullptr;
@@ -134,6 +138,7 @@ struct TableKey {
 };
 
 static struct {
+    int tile_streams = -1;                          // side streams for small independent precompute dispatches (-1: PBR_TILE_STREAMS or 4)
     bool init = false;
     int device = -1;
     GPU_Sampler samplers[6];
@@ -699,7 +704,9 @@ static void reset_graph(GPU_Graph* g) {
 GPU_API void GPU_DestroyGraph(GPU_Graph* g) {
     GPU_REQUIRE_V(g, "GPU_DestroyGraph: NULL graph");            // the reference does not accept NULL here (gpu_vulkan.c:2393-2404)
     (void)hipStreamSynchronize(g->stream);
+    for (hipStream_t s : g->side) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->sync_ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(g->stream);
     delete g;
 }
@@ -1157,18 +1164,32 @@ template <class F>
 static void timed(GPU_Graph* g, const std::string& name, size_t& ev_used, F launch) {
     if (G.timing) {
         hipEvent_t a = next_event(g, ev_used);
-        HIP_OK(hipEventRecord(a, g->stream));
+        HIP_OK(hipEventRecord(a, g->cur));
         launch();
         hipEvent_t b = next_event(g, ev_used);
-        HIP_OK(hipEventRecord(b, g->stream));
+        HIP_OK(hipEventRecord(b, g->cur));
         g->timed_names.push_back(name);
     } else {
         launch();
     }
 }
 
+static hipEvent_t next_sync_event(GPU_Graph* g) {
+    if (g->sync_used == g->sync_ev.size()) { hipEvent_t e; HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); g->sync_ev.push_back(e); }
+    return g->sync_ev[g->sync_used++];
+}
+
+// Lazily built twins (apron, cells) enqueued on a side stream must be visible to the launches that follow on every other stream.
+static void publish_side_work(GPU_Graph* g) {
+    if (g->cur == g->stream) return;
+    hipEvent_t e = next_sync_event(g);
+    HIP_OK(hipEventRecord(e, g->cur));
+    HIP_OK(hipStreamWaitEvent(g->stream, e, 0));
+    for (hipStream_t s : g->side) if (s != g->cur) HIP_OK(hipStreamWaitEvent(s, e, 0));
+}
+
 static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
-    hipStream_t st = g->stream;
+    hipStream_t st = g->cur;
     switch (op.kind) {
     case Op_Dispatch: {
         if (op.cpipe->kernel == Kernel_LightgridSweep) {
@@ -1208,6 +1229,7 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
         if (!et->bordered_valid) {
             timed(g, "apron.env", ev_used, [&] { ensure_bordered(et, st); });
             if (!et->bordered_valid) return;
+            publish_side_work(g);
         }
         int W = (int)et->base.width, levels = (int)et->base.mip_level_count;
         float lod; int n; float divisor, alpha = 0.0f; DeviceTable* tab = nullptr;
@@ -1240,7 +1262,10 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
         int n_src = W >> l; if (n_src < 1) n_src = 1;
         const void* src = (const char*)et->bordered + pbrk_bordered_level_offset(W, l) * 16;
         const void* cells = nullptr;
-        if (!copy) { if (cells_ready(et, l)) cells = ensure_cells(et, l, st); else timed(g, "cells.env", ev_used, [&] { cells = ensure_cells(et, l, st); }); }
+        if (!copy) {
+            if (cells_ready(et, l)) cells = ensure_cells(et, l, st);
+            else { timed(g, "cells.env", ev_used, [&] { cells = ensure_cells(et, l, st); }); publish_side_work(g); }
+        }
         timed(g, nm, ev_used, [&] {
             int rc = copy ? pbrk_prefilter_copy(src, n_src, out_ptr, (int)size, (int)op.face0, (int)op.face1, (int)op.row0, (int)op.row1, st)
                           : pbrk_mc_filter(src, cells, n_src, tab->dev, tab->count, divisor, alpha, out_ptr, (int)size,
@@ -1454,7 +1479,54 @@ GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
     GPU_REQUIRE_V(g->in_pass == nullptr && g->preparing == nullptr, "GPU_GraphSubmit: render pass still open");
     g->timed_names.clear(); g->timed_ms.clear();
     size_t ev_used = 0;
-    for (Op& op : g->ops) exec_op(g, op, ev_used);
+    g->sync_used = 0;
+    g->cur = g->stream;
+    // Row-ranged precompute dispatches (the work units of a partitioned job) are too small to keep 256 CUs x 8 waves busy one
+    // at a time: consecutive ones whose outputs are disjoint and which do not read each other's output go round-robin onto
+    // side streams, fenced by a fork event before the first and join events after the last.  Everything else stays in order.
+    if (G.tile_streams < 0) { const char* e = getenv("PBR_TILE_STREAMS"); G.tile_streams = e ? atoi(e) : 4; }
+    if (G.tile_streams > 16) G.tile_streams = 16;
+    const int n_side = G.tile_streams;
+    struct Wr { TextureImpl* t; uint32_t mip, f0, f1, r0, r1; };
+    std::vector<Wr> writes; std::vector<TextureImpl*> reads;
+    bool open = false; size_t rr = 0;
+    auto close_region = [&] {
+        if (!open) return;
+        for (hipStream_t s : g->side) { hipEvent_t e = next_sync_event(g); HIP_OK(hipEventRecord(e, s)); HIP_OK(hipStreamWaitEvent(g->stream, e, 0)); }
+        writes.clear(); reads.clear(); open = false; g->cur = g->stream;
+    };
+    for (Op& op : g->ops) {
+        bool tile = n_side >= 2 && op.kind == Op_Dispatch && op.rows_explicit &&
+                    (op.cpipe->kernel == Kernel_Prefilter || op.cpipe->kernel == Kernel_Irradiance);
+        Slot* out = tile ? named_slot(op.set, "OUTPUT") : nullptr;
+        Slot* env = tile ? named_slot(op.set, "TEX_ENV_CUBE") : nullptr;
+        // a launch of several full-chip rounds (2048 resident workgroups x 256 texels each) gains nothing from company and keeps
+        // its own event timing clean: only smaller ones are overlapped
+        if (tile && out && out->tex && (uint64_t)(op.face1 - op.face0) * (op.row1 - op.row0) * mip_dim(out->tex->base.width, out->mip) >= 2000000ull) tile = false;
+        if (!tile || !out || !env || !out->tex || !env->tex) { close_region(); exec_op(g, op, ev_used); continue; }
+        Wr w = {out->tex, out->mip, op.face0, op.face1, op.row0, op.row1};
+        bool clash = w.t == env->tex;
+        for (const Wr& o : writes) {
+            if (o.t == env->tex) clash = true;
+            if (o.t == w.t && o.mip == w.mip && o.f0 < w.f1 && w.f0 < o.f1 && o.r0 < w.r1 && w.r0 < o.r1) clash = true;
+        }
+        for (TextureImpl* r : reads) if (r == w.t) clash = true;
+        if (clash) close_region();
+        if (w.t == env->tex) { exec_op(g, op, ev_used); continue; }        // reads what it writes: never overlapped
+        if (!open) {
+            while ((int)g->side.size() > n_side) { (void)hipStreamSynchronize(g->side.back()); (void)hipStreamDestroy(g->side.back()); g->side.pop_back(); }
+            while ((int)g->side.size() < n_side) { hipStream_t s; HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); g->side.push_back(s); }
+            hipEvent_t e = next_sync_event(g);
+            HIP_OK(hipEventRecord(e, g->stream));
+            for (hipStream_t s : g->side) HIP_OK(hipStreamWaitEvent(s, e, 0));
+            open = true;
+        }
+        writes.push_back(w); reads.push_back(env->tex);
+        g->cur = g->side[rr++ % g->side.size()];
+        exec_op(g, op, ev_used);
+        g->cur = g->stream;
+    }
+    close_region();
     g->submitted = true;
 }
 
@@ -1471,6 +1543,7 @@ GPU_API void GPU_GraphWait(GPU_Graph* g) {
 }
 
 GPU_API void GPUX_EnableOpTiming(int enable) { G.timing = enable != 0; }
+GPU_API void GPUX_SetTileStreams(int count) { G.tile_streams = count < 0 ? -1 : count; }
 GPU_API uint32_t GPUX_GraphTimedOpCount(GPU_Graph* g) { return g ? (uint32_t)g->timed_ms.size() : 0; }
 GPU_API const char* GPUX_GraphTimedOpName(GPU_Graph* g, uint32_t i) { return (g && i < g->timed_names.size()) ? g->timed_names[i].c_str() : ""; }
 GPU_API float GPUX_GraphTimedOpMs(GPU_Graph* g, uint32_t i) { return (g && i < g->timed_ms.size()) ? g->timed_ms[i] : 0.0f; }

@@ -164,7 +164,7 @@ PROTOTYPES = {
     "GPUX_MakeTextureExternal": (TexP, [C.c_int, U32, U32, U32, C.c_int, VP, C.c_uint64]),
     "GPUX_TextureTotalBytes": (C.c_uint64, [TexP]), "GPUX_TextureMipOffset": (C.c_uint64, [TexP, U32]),
     "GPUX_MakeCubemapFromEquirect": (TexP, [VP, U32, U32, U32, C.c_int]),
-    "GPUX_GraphStream": (VP, [VP]), "GPUX_EnableOpTiming": (None, [C.c_int]), "GPUX_GraphTimedOpCount": (U32, [VP]),
+    "GPUX_GraphStream": (VP, [VP]), "GPUX_EnableOpTiming": (None, [C.c_int]), "GPUX_SetTileStreams": (None, [C.c_int]), "GPUX_GraphTimedOpCount": (U32, [VP]),
     "GPUX_GraphTimedOpName": (C.c_char_p, [VP, U32]), "GPUX_GraphTimedOpMs": (C.c_float, [VP, U32]),
     # --- host layer (include/pbr_host.h) ---
     "PBR_DecodeHDR": (VP, [VP, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
