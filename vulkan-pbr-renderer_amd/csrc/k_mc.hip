@@ -40,8 +40,7 @@ __device__ __forceinline__ f3 tap_rgb(__amdgpu_buffer_rsrc_t rs, int voff, int s
 // "cells" layout: for every tap position (face, j0, i0), i0/j0 in [0, n], the 2x2 RGB footprint
 // {t00, t10, t01, t11} stored contiguously (48 B) -> three 16-byte loads serve a whole bilinear fetch.
 typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void taps_cells(__amdgpu_buffer_rsrc_t rc, int cell, f3& t00, f3& t10, f3& t01, f3& t11) {
-    int voff = cell * 48;
+__device__ __forceinline__ void taps_cells(__amdgpu_buffer_rsrc_t rc, int voff, f3& t00, f3& t10, f3& t01, f3& t11) {
     u32x4c A = __builtin_amdgcn_raw_buffer_load_b128(rc, voff, 0, 0);
     u32x4c Bq = __builtin_amdgcn_raw_buffer_load_b128(rc, voff + 16, 0, 0);
     u32x4c Cq = __builtin_amdgcn_raw_buffer_load_b128(rc, voff + 32, 0, 0);
@@ -62,12 +61,16 @@ __device__ __forceinline__ f3 sample_bordered(__amdgpu_buffer_rsrc_t rs, f3 L, f
     float u = fmaf(sc, h, off);                                  // s*n - 0.5 + 1 (bordered), in [0.5, n + 0.5]
     float v = fmaf(tc, h, off);
     float a = __builtin_amdgcn_fractf(u), b = __builtin_amdgcn_fractf(v);
-    int i0 = (int)u, j0 = (int)v, face = (int)fid;
     f3 t00, t10, t01, t11;
     if (CELLS) {
-        int nc = nb - 1;                                         // n + 1 tap positions per edge
-        taps_cells(rs, (face * nc + j0) * nc + i0, t00, t10, t01, t11);
+        // Cell byte offset in fp32: cells exist for n <= 512 only, so face*nc + j0, the cell index (< 6*513^2 < 2^24) and
+        // 48*cell (= 16 * an integer < 2^24) are all exact -- six full-rate instructions instead of three conversions and
+        // three quarter-rate integer multiplies (this loop is as VALU-bound as it is L1-bound).
+        float ncf = (float)(nb - 1);                             // n + 1 tap positions per edge
+        float cellf = fmaf(fmaf(fid, ncf, floorf(v)), ncf, floorf(u));
+        taps_cells(rs, (int)(cellf * 48.0f), t00, t10, t01, t11);
     } else {
+        int i0 = (int)u, j0 = (int)v, face = (int)fid;
         int voff = ((face * nb + j0) * nb + i0) << 4;
         t00 = tap_rgb(rs, voff, 0); t10 = tap_rgb(rs, voff + 16, 0);
         t01 = tap_rgb(rs, voff, row_bytes); t11 = tap_rgb(rs, voff + 16, row_bytes);
@@ -595,7 +598,7 @@ extern "C" int pbrk_mc_filter(const void* src_bordered_level, const void* src_ce
     McArgs a;
     a.src = (const float4*)src_bordered_level; a.n_src = n_src; a.src_bytes = (unsigned)src_bytes;
     a.cells = (const float4*)src_cells; a.cells_bytes = (unsigned)pbrk_cells_bytes(n_src);
-    if (src_cells && pbrk_cells_bytes(n_src) > 0x7FFFFFFFu) return PBRK_E_ARG;
+    if (src_cells && n_src > 512) return PBRK_E_ARG;            // the kernel forms cell offsets in exact fp32 (n + 1 <= 513)
     a.tab = (const float4*)table4; a.n_tab = n_entries;
     a.divisor = divisor; a.alpha = alpha;
     a.out = (float4*)out; a.size = out_size;
