@@ -308,7 +308,7 @@ def main():
         if nm.startswith("K4b.prefilter_mc.mip") and world == 1:
             size = max(1, spec_size >> int(nm.rsplit("mip", 1)[1]))
             if size >= 512:
-                ent["traffic"] = traffic_for("void k_mc_filter<1, 4, true>", 6 * size * size)
+                ent["traffic"] = traffic_for("void k_mc_filter<4, 4, true>", 6 * size * size * 4)      # 4 sample slices per texel
         elif nm.startswith("K4a.") and world == 1:
             ent["traffic"] = traffic_for("k_prefilter_copy", 256 * 64 * 256)
         elif nm == "K2.mip_chain" and world == 1:
@@ -392,7 +392,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "env": f"procedural HDR cube {W}^2 x6 RGBA32F (seed {seed:#x}, RGBE round-tripped)",
                        "texels_per_step": total_texels,
-                       "parallelism": "single GPU" if world == 1 else f"{world} ranks, cost-partitioned (mip,face,row-tile) units, 1 grouped RCCL send/recv gather per step"},
+                       "parallelism": "single GPU" if world == 1 else f"{world} ranks, weighted linear partition of output rows (3-8 dispatches per rank), 1 grouped RCCL send/recv gather per step"},
             "roofline": roofline, "roofline_hbm": roofline_hbm, "kernels": kernels[:12],
             "cpu_baseline": cpu, "extra": extra,
         }

@@ -66,9 +66,11 @@ void PBR_DestroyIBLPipelines(PBR_IBLPipelines* p);
 void PBR_RecordUnits(PBR_IBLPipelines* p, GPU_Graph* graph, GPU_DescriptorArena* arena, GPU_Texture* tex_env_cube,
                      const PBR_IBLMaps* maps, const PBR_WorkUnit* units, uint32_t unit_count);
 
-/* Enumerates the precompute's work units (prefilter mips down to min_size, optionally irradiance) cut
- * into row tiles, and assigns them to `world` ranks by cost (greedy longest-first).
- * Returns the number of units written to out (<= capacity) for `rank`; rank < 0 lists all units. */
+/* Splits the precompute (prefilter mips down to min_size, optionally irradiance) over `world` ranks: the rows of
+ * the big levels, laid end to end and weighted with the measured time per sample evaluation of their level, are cut into
+ * `world` contiguous shares of equal cost, so a rank receives at most two partial faces plus runs of whole faces (one unit per
+ * run); the copy level is pinned to rank 0 (where results are gathered), cheap levels stay whole.  world = 1: one unit per level.
+ * Returns the number of units written to out (<= capacity) for `rank`; rank < 0 lists all units.  Deterministic. */
 uint32_t PBR_PartitionIBL(uint32_t specular_size, uint32_t min_size, uint32_t irradiance_size, uint32_t env_size,
                           int world, int rank, PBR_WorkUnit* out, uint32_t capacity);
 

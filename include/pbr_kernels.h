@@ -75,6 +75,8 @@ int pbrk_box_downsample(const void* src, int ns, void* dst, int nlayers, void* s
 /* ---- border build: pyramid -> bordered pyramid (seamless-cube apron; sampler state of
  *      src/gpu/gpu_vulkan.c:613-634 applied to a cube view). */
 int pbrk_border_build(const void* pyramid, void* bordered, int W, int levels, void* stream);
+/* the same for levels [level0, level1) of a `levels`-deep chain only (the other levels of `bordered` are left alone) */
+int pbrk_border_build_range(const void* pyramid, void* bordered, int W, int levels, int level0, int level1, void* stream);
 
 /* ---- K6 (extension): equirectangular RGBA32F panorama [h][w] -> cube level 0 [6][size][size].
  * Z-up: u = atan2(y,x)/2pi + .5 (wraps), v = acos(z/|d|)/pi (clamps); bilinear; angles in fp64. */

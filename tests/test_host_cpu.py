@@ -168,6 +168,15 @@ def test_partition_covers_every_texel_once_and_balances(L):
         # rank < 0 lists everything; partition is deterministic
         assert len(units_of(spec, 1, irr, 2048, world, -1)) == sum(len(units_of(spec, 1, irr, 2048, world, r)) for r in range(world))
         assert units_of(spec, 1, irr, 2048, world, 0) == units_of(spec, 1, irr, 2048, world, 0)
+    # communication-aware: the copy level stays on rank 0 (where results are gathered), rank 0 holds most of the byte-heavy mip 1, the
+    # other ranks send about the same number of bytes each, and nobody gets more than a handful of dispatches
+    sent = []
+    for r in range(8):
+        us = units_of(4096, 1, 128, 2048, 8, r)
+        assert len(us) <= 10
+        assert all(r == 0 for u in us if u[0] == 0 and u[1] == 0) and (r != 0 or any(u[0] == 0 and u[1] == 0 for u in us))
+        sent.append(sum((u[3] - u[2]) * (u[5] - u[4]) * (128 if u[0] == 1 else 4096 >> u[1]) * 16 for u in us if not (u[0] == 0 and u[1] == 0)))
+    assert max(sent[1:]) <= 1.15 * min(sent[1:]) and sent[0] > 2 * max(sent[1:])
     # reference stop rule: `if (size < 16) break;` (render.cpp:566)
     assert {u[1] for u in units_of(256, 16, 0, 256, 1, 0)} == {0, 1, 2, 3, 4}
 

@@ -34,3 +34,10 @@ for rank in ranks:
         ts.append((time.perf_counter() - t0) * 1e3)
         L.GPU_ResetDescriptorArena(arena)
     print(f"world {world} rank {rank}: {n} units, {min(ts[1:]):.2f} ms (ideal {137.5 / world:.2f} ms)", flush=True)
+    if os.environ.get("RANK_TIME_UNITS") == "1":
+        from collections import Counter
+        c = Counter((u.kind, u.mip) for u in units[:n])
+        cost = Counter()
+        for u in units[:n]:
+            cost[(u.kind, u.mip)] += u.cost
+        print("   ", {k: (c[k], round(cost[k] / 1e9, 2)) for k in sorted(c)}, flush=True)

@@ -63,7 +63,8 @@ struct TextureImpl {
     uint32_t texel_bytes = 0;
     void* bordered = nullptr;         // bordered pyramid twin (RGBA32F cubes only), built on demand
     size_t bordered_bytes = 0;
-    bool bordered_valid = false;
+    bool bordered_valid = false;                   // apron twin valid for levels >= bordered_from
+    int bordered_from = 0;
     bool owns_memory = true;          // false: GPUX_MakeTextureExternal (caller-owned HBM, e.g. a torch tensor)
     // 2x2-footprint "cells" twin of the levels with n <= 512 (levels cells_first.., back to back), built per level on demand
     void* cells = nullptr; int cells_first = 0; std::vector<size_t> cells_off; std::vector<char> cells_valid;
@@ -1101,19 +1102,22 @@ GPU_API void GPU_OpClearDepthStencil(GPU_Graph* g, GPU_Texture* dst, uint32_t mi
 // ------------------------------------------------------------------------------------------
 // execution
 // ------------------------------------------------------------------------------------------
-static bool ensure_bordered(TextureImpl* t, hipStream_t st) {
-    if (t->bordered_valid) return true;
-    for (char& v : t->cells_valid) v = 0;
+static bool ensure_bordered(TextureImpl* t, hipStream_t st, int first_level = 0) {
     int W = (int)t->base.width, levels = (int)t->base.mip_level_count;
+    if (first_level < 0) first_level = 0;
+    if (first_level > levels - 1) first_level = levels - 1;
+    if (t->bordered_valid && t->bordered_from <= first_level) return true;
     if (!t->bordered) {
         t->bordered_bytes = pbrk_bordered_pyramid_texels(W, levels) * 16;
         hipError_t e = hipMalloc(&t->bordered, t->bordered_bytes);
         if (e != hipSuccess) { gpu_fail("bordered twin allocation (%zu bytes) failed: %s", t->bordered_bytes, hipGetErrorString(e)); return false; }
     }
-    int rc = pbrk_border_build(t->dev, t->bordered, W, levels, st);
+    // only the levels somebody samples get an apron: the precompute never touches level 0 of its source (400 MB at 2048^2)
+    int end = t->bordered_valid ? t->bordered_from : levels;
+    if (!t->bordered_valid) for (char& v : t->cells_valid) v = 0;
+    int rc = pbrk_border_build_range(t->dev, t->bordered, W, levels, first_level, end, st);
     if (rc != PBRK_OK) { gpu_fail("border build failed (%d)", rc); return false; }
-    t->bordered_valid = true;
-    for (char& v : t->cells_valid) v = 0;
+    t->bordered_valid = true; t->bordered_from = first_level;
     return true;
 }
 
@@ -1226,11 +1230,6 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
         }
         Slot* env = named_slot(op.set, "TEX_ENV_CUBE");
         TextureImpl* et = env->tex;
-        if (!et->bordered_valid) {
-            timed(g, "apron.env", ev_used, [&] { ensure_bordered(et, st); });
-            if (!et->bordered_valid) return;
-            publish_side_work(g);
-        }
         int W = (int)et->base.width, levels = (int)et->base.mip_level_count;
         float lod; int n; float divisor, alpha = 0.0f; DeviceTable* tab = nullptr;
         bool copy = false;
@@ -1259,6 +1258,11 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
         if (l < 0) l = 0;
         if (l > levels - 1) l = levels - 1;                     // sampler clamps LOD to the chain
         if ((float)l != lod && lod < (float)(levels - 1)) { gpu_fail("%s: fractional source LOD %g is not supported by the precompute kernels", nm, lod); return; }
+        if (!et->bordered_valid || et->bordered_from > l) {
+            timed(g, "apron.env", ev_used, [&] { ensure_bordered(et, st, l); });
+            if (!et->bordered_valid || et->bordered_from > l) return;
+            publish_side_work(g);
+        }
         int n_src = W >> l; if (n_src < 1) n_src = 1;
         const void* src = (const char*)et->bordered + pbrk_bordered_level_offset(W, l) * 16;
         const void* cells = nullptr;
@@ -1335,7 +1339,7 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
         a.emissive = named_slot(s, "GBUFFER_EMISSIVE")->tex->dev;
         a.depth = named_slot(s, "GBUFFER_DEPTH")->tex->dev;
         TextureImpl* pre = named_slot(s, "PREFILTERED_ENV_MAP")->tex;
-        if (!pre->bordered_valid) { timed(g, "apron.prefiltered", ev_used, [&] { ensure_bordered(pre, g->stream); }); if (!pre->bordered_valid) return; }
+        if (!pre->bordered_valid || pre->bordered_from > 0) { timed(g, "apron.prefiltered", ev_used, [&] { ensure_bordered(pre, g->stream); }); if (!pre->bordered_valid) return; }
         a.prefiltered_bordered = pre->bordered; a.prefiltered_size = (int)pre->base.width; a.prefiltered_levels = (int)pre->base.mip_level_count;
         {
             bool all = true;
@@ -1348,7 +1352,7 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
         if (op.gpipe->shade_flags & GPUX_Shade_IBL) {
             a.flags |= PBRK_SHADE_IBL;
             TextureImpl* irr = named_slot(s, "TEX_IRRADIANCE_MAP")->tex;
-            if (!irr->bordered_valid) { timed(g, "apron.irradiance", ev_used, [&] { ensure_bordered(irr, g->stream); }); if (!irr->bordered_valid) return; }
+            if (!irr->bordered_valid || irr->bordered_from > 0) { timed(g, "apron.irradiance", ev_used, [&] { ensure_bordered(irr, g->stream); }); if (!irr->bordered_valid) return; }
             a.irradiance_bordered = irr->bordered; a.irradiance_size = (int)irr->base.width;
             a.irradiance_cells = ensure_cells(irr, 0, g->stream);
             TextureImpl* lut = named_slot(s, "BRDF_INTEGRATION_MAP")->tex;
@@ -1474,6 +1478,21 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
     }
 }
 
+// sample evaluations per output texel of a precompute dispatch (the same decoding of the push constants as exec_op)
+static double dispatch_samples_per_texel(const Op& op) {
+    GPUX_IBLConstants c = {0, 0.0f, 0.0f, 0};
+    bool explicit_c = op.push_size == sizeof(GPUX_IBLConstants);
+    if (explicit_c) memcpy(&c, op.push, sizeof c);
+    else if (op.push_size >= 4) memcpy(&c.mip_level, op.push, 4);
+    if (op.cpipe->kernel == Kernel_Irradiance) return (explicit_c && c.sample_count > 0) ? c.sample_count : 1024;
+    if (c.mip_level == 0) return 4.0;                                       // the copy level: one bilinear fetch, HBM-bound
+    int n = (explicit_c && c.sample_count > 0) ? c.sample_count : 8192;
+    float rough = explicit_c ? c.roughness : reference_roughness(c.mip_level);
+    if (!(rough > 0.0f)) return n;
+    DeviceTable* tab = get_table(0, n, rough, 0);                           // cached; only entries with non-zero weight are kept
+    return tab ? (double)tab->count : (double)n;
+}
+
 GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
     GPU_REQUIRE_V(g && !g->submitted, "GPU_GraphSubmit: graph is NULL or already submitted");
     GPU_REQUIRE_V(g->in_pass == nullptr && g->preparing == nullptr, "GPU_GraphSubmit: render pass still open");
@@ -1500,9 +1519,12 @@ GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
                     (op.cpipe->kernel == Kernel_Prefilter || op.cpipe->kernel == Kernel_Irradiance);
         Slot* out = tile ? named_slot(op.set, "OUTPUT") : nullptr;
         Slot* env = tile ? named_slot(op.set, "TEX_ENV_CUBE") : nullptr;
-        // a launch of several full-chip rounds (2048 resident workgroups x 256 texels each) gains nothing from company and keeps
-        // its own event timing clean: only smaller ones are overlapped
-        if (tile && out && out->tex && (uint64_t)(op.face1 - op.face0) * (op.row1 - op.row0) * mip_dim(out->tex->base.width, out->mip) >= 2000000ull) tile = false;
+        // a launch of several full-chip rounds (2048 resident workgroups x 256 texels x 8192 samples each) gains nothing from
+        // company and keeps its own event timing clean: only smaller ones are overlapped
+        if (tile && out && out->tex) {
+            double texels = (double)(op.face1 - op.face0) * (op.row1 - op.row0) * mip_dim(out->tex->base.width, out->mip);
+            if (texels * dispatch_samples_per_texel(op) >= 2.0e6 * 8192.0) tile = false;
+        }
         if (!tile || !out || !env || !out->tex || !env->tex) { close_region(); exec_op(g, op, ev_used); continue; }
         Wr w = {out->tex, out->mip, op.face0, op.face1, op.row0, op.row1};
         bool clash = w.t == env->tex;

@@ -126,15 +126,20 @@ extern "C" int pbrk_box_downsample(const void* src, int ns, void* dst, int nlaye
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
 
-extern "C" int pbrk_border_build(const void* pyramid, void* bordered, int W, int levels, void* stream) {
+extern "C" int pbrk_border_build_range(const void* pyramid, void* bordered, int W, int levels, int level0, int level1, void* stream) {
     if (!pyramid || !bordered || W <= 0 || levels < 1 || levels > pbrk_mip_count(W, W)) return PBRK_E_ARG;
-    for (int l = 0; l < levels; ++l) {
+    if (level0 < 0 || level1 > levels || level0 > level1) return PBRK_E_ARG;
+    for (int l = level0; l < level1; ++l) {
         int n = lvl_size(W, l);
         const float4* src = (const float4*)pyramid + pbrk_level_offset(W, l);
         float4* dst = (float4*)bordered + pbrk_bordered_level_offset(W, l);
         hipLaunchKernelGGL(k_border_level, dim3((n + 2 + 63) / 64, (n + 2 + 3) / 4, 6), dim3(256), 0, (hipStream_t)stream, src, dst, n);
     }
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+}
+
+extern "C" int pbrk_border_build(const void* pyramid, void* bordered, int W, int levels, void* stream) {
+    return pbrk_border_build_range(pyramid, bordered, W, levels, 0, levels, stream);
 }
 
 extern "C" int pbrk_prefilter_copy(const void* src_bordered_level, int n_src, void* out, int out_size,

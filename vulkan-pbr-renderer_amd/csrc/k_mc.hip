@@ -611,13 +611,14 @@ extern "C" int pbrk_mc_filter(const void* src_bordered_level, const void* src_ce
     // Sample-split factor S depends on the LEVEL size only (not on the dispatched sub-range), so that a
     // sharded dispatch sums in exactly the same order as a full one (bit-identical results).
     size_t texels = (size_t)6 * out_size * out_size;
-    // enough workgroups to fill 256 CUs several times over: split the sample table when texels are few
+    // Enough workgroups to fill 256 CUs several times over: split the sample table when texels are few.  Never fewer than 4
+    // slices: a 256-texel workgroup walking all 8192 samples runs for ~5.6 ms, and a share of the level (one rank's tiles)
+    // that is only a few such rounds long loses up to a round in its tail; 4 slices of 64 texels (one wave each, table
+    // entries still wave-uniform scalar loads) cost nothing and cut that tail by four (8-way share: 18.1 -> 17.3 ms mean).
     size_t want_blocks = 2048;
-    int S = 1;
+    int S = 4;
     while (S < 256 && texels * (size_t)S < want_blocks * 256) S <<= 1;
     switch (S) {
-    case 1: launch_mc<1>(a, nfaces, st); break;
-    case 2: launch_mc<2>(a, nfaces, st); break;
     case 4: launch_mc<4>(a, nfaces, st); break;
     case 8: launch_mc<8>(a, nfaces, st); break;
     case 16: launch_mc<16>(a, nfaces, st); break;

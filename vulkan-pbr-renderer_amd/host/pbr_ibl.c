@@ -186,31 +186,32 @@ static double samples_per_texel(uint32_t mip) {
     return 8192.0;
 }
 
-/* Measured time per sample-evaluation relative to mip 2 (one MI355X, C4): the MC kernel is a little faster where
- * most weights are large (mip 1) and slower where levels are small; the irradiance pass reads a tiny level.  The copy mip moves
- * 16 B per texel at ~3.4 TB/s, i.e. as long as ~3.8 sample-evaluations per texel.  Used for balancing only; unit.cost stays
- * the plain count. */
+/* Measured time per sample-evaluation relative to mip 2 (one MI355X, C4, shares of an 8-way split run through
+ * tools/rank_time.py): the MC kernel is a little faster where most weights are large (mip 1); the irradiance pass
+ * reads a tiny level.  The copy mip moves 16 B per texel at ~3.4 TB/s, i.e. as long as ~3.8 sample-evaluations per texel.
+ * Used for balancing only; unit.cost stays the plain count. */
 static double time_weight(const PBR_WorkUnit* u) {
     if (u->kind == PBR_Unit_Irradiance) return 1.24;
     switch (u->mip) {
     case 0: return 3.8;
-    case 1: return 0.965;
+    case 1: return 0.96;
     case 2: return 1.0;
-    case 3: return 1.04;
-    case 4: return 1.13;
-    case 5: return 1.07;
+    case 3: return 1.0;
+    case 4: return 1.1;
+    case 5: return 1.1;
     default: return 1.1;
     }
 }
 
-static int cmp_cost_desc(const void* a, const void* b) {
-    double ca = ((const PBR_WorkUnit*)a)->cost, cb = ((const PBR_WorkUnit*)b)->cost;
-    if (ca != cb) return ca < cb ? 1 : -1;
-    const PBR_WorkUnit* x = (const PBR_WorkUnit*)a; const PBR_WorkUnit* y = (const PBR_WorkUnit*)b;   /* deterministic tie-break */
-    if (x->kind != y->kind) return x->kind < y->kind ? -1 : 1;
-    if (x->mip != y->mip) return x->mip < y->mip ? -1 : 1;
-    if (x->face0 != y->face0) return x->face0 < y->face0 ? -1 : 1;
-    return x->row0 < y->row0 ? -1 : (x->row0 > y->row0);
+/* Faces 0 and 1 (+-X) contain the pole of the tangent frame (`some_vector`): neighbouring texels there take their samples at
+ * different azimuths, the footprints of a wave overlap less, and the same number of sample evaluations takes longer.  Run
+ * alone, single-face dispatches differ by +5 %, +8 %, +25 %, +14 %, +5 % for mips 1-5 (tools/face_time.py, C4); next to
+ * other dispatches about half of that remains, which is what balances the shares of a 4- and 8-way split
+ * (tools/rank_time.py: 17.4-18.05 ms at 8 ranks, 34.4-35.2 ms at 4). */
+static double face_weight(const PBR_WorkUnit* u, uint32_t face) {
+    static const double pole[6] = {1.0, 1.03, 1.04, 1.12, 1.1, 1.05};
+    if (u->kind != PBR_Unit_Prefilter || face > 1 || u->mip > 5) return 1.0;
+    return pole[u->mip];
 }
 
 uint32_t PBR_PartitionIBL(uint32_t specular_size, uint32_t min_size, uint32_t irradiance_size, uint32_t env_size,
@@ -227,7 +228,6 @@ uint32_t PBR_PartitionIBL(uint32_t specular_size, uint32_t min_size, uint32_t ir
         if (s == 1) break;
     }
     if (irradiance_size) total += 6.0 * irradiance_size * irradiance_size * 1024.0;
-    double target = total / (8.0 * world);
     if (world == 1 && rank <= 0) {
         /* single GPU: one dispatch per output level (the reference's own granularity, render.cpp:564-580) */
         uint32_t n1 = 0;
@@ -245,53 +245,140 @@ uint32_t PBR_PartitionIBL(uint32_t specular_size, uint32_t min_size, uint32_t ir
         }
         return n1;
     }
-    uint32_t cap_all = 0, n = 0;
-    PBR_WorkUnit* all = NULL;
-    for (int pass = 0; pass < 2; ++pass) {
-        n = 0;
-        for (uint32_t m = 0; m <= mips; ++m) {
-            int irr = m == mips;
-            if (irr && !irradiance_size) break;
-            uint32_t size = irr ? irradiance_size : (specular_size >> m ? specular_size >> m : 1);
-            double per_row = (double)size * (irr ? 1024.0 : samples_per_texel(m));
-            uint32_t rows_per_tile = (uint32_t)(target / per_row);
-            if (rows_per_tile < 1) rows_per_tile = 1;
-            if (rows_per_tile > size) rows_per_tile = size;
-            /* keep tiles a multiple of 16 rows where possible (kernel tile height) */
-            if (rows_per_tile >= 16) rows_per_tile &= ~15u;
-            for (uint32_t f = 0; f < 6; ++f)
-                for (uint32_t r = 0; r < size; r += rows_per_tile) {
-                    if (pass == 1) {
-                        PBR_WorkUnit* u = &all[n];
-                        u->kind = irr ? PBR_Unit_Irradiance : PBR_Unit_Prefilter;
-                        u->mip = irr ? 0 : m; u->face0 = f; u->face1 = f + 1;
-                        u->row0 = r; u->row1 = r + rows_per_tile < size ? r + rows_per_tile : size;
-                        u->cost = per_row * (u->row1 - u->row0);
-                    }
-                    ++n;
-                }
+    /* N ranks: contiguous shares of the row sequence.
+     *
+     * A launch needs thousands of workgroups in flight to hide the gather latency of the Monte-Carlo kernel, so a rank should
+     * receive FEW, LARGE dispatches; balance, on the other hand, wants fine granularity.  Both are had by laying all rows of
+     * all big levels end to end (level by level, face by face), weighting each row with the measured time per sample
+     * evaluation of its level, and cutting that sequence into `world` shares of equal weighted cost: every rank gets at most
+     * two partial faces plus runs of whole faces (merged into one dispatch per level), and the cut positions are exact to a
+     * few rows.  Outputs are gathered on rank 0, so the copy level (75 % of the output bytes, 0.4 % of the compute) is pinned
+     * to rank 0 and never crosses xGMI; levels cheaper than 1/16 of a share stay whole (their launches are latency-bound: six
+     * single-face dispatches would take six times as long as one) and go to whichever rank has the most room left. */
+    typedef struct { int irr; uint32_t mip, size; double raw_row, w_row[6], w_level; int whole; } Level;
+    Level lv[40];
+    uint32_t nl = 0;
+    double total_w = 0.0;
+    for (uint32_t m = 0; m <= mips && nl < 40; ++m) {
+        int irr = m == mips;
+        if (irr && !irradiance_size) break;
+        Level* l = &lv[nl++];
+        l->irr = irr; l->mip = irr ? 0 : m;
+        l->size = irr ? irradiance_size : (specular_size >> m ? specular_size >> m : 1);
+        PBR_WorkUnit probe; memset(&probe, 0, sizeof probe);
+        probe.kind = irr ? PBR_Unit_Irradiance : PBR_Unit_Prefilter; probe.mip = l->mip;
+        l->raw_row = (double)l->size * (irr ? 1024.0 : samples_per_texel(m));
+        l->whole = 0; l->w_level = 0.0;
+        for (uint32_t f = 0; f < 6; ++f) {
+            l->w_row[f] = l->raw_row * time_weight(&probe) * face_weight(&probe, f);
+            l->w_level += l->size * l->w_row[f];
         }
-        if (pass == 0) { cap_all = n; all = (PBR_WorkUnit*)malloc(sizeof(PBR_WorkUnit) * (cap_all ? cap_all : 1)); }
+        total_w += l->w_level;
     }
-    qsort(all, n, sizeof *all, cmp_cost_desc);
-    /* Communication-aware greedy assignment.  Outputs are gathered on rank 0, so the copy mip (mip 0: 75 % of the
-     * output bytes, 0.4 % of the compute) stays on rank 0 and never crosses xGMI; its cost is charged to rank 0's
-     * load first.  Everything else: longest-first onto the least loaded rank (ties -> lowest rank). */
-    double* load = (double*)calloc((size_t)world, sizeof(double));
-    uint32_t written = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        for (uint32_t k = 0; k < n; ++k) {
-            int pinned = all[k].kind == PBR_Unit_Prefilter && all[k].mip == 0;
-            if ((pass == 0) != pinned) continue;
-            int best = 0;
-            if (!pinned) for (int r = 1; r < world; ++r) if (load[r] < load[best]) best = r;
-            load[best] += all[k].cost * time_weight(&all[k]);
-            if (rank < 0 || best == rank) {
-                if (written < capacity && out) out[written] = all[k];
-                ++written;
+    double budget = total_w / world;
+    double* room = (double*)malloc(sizeof(double) * (size_t)world);
+    for (int r = 0; r < world; ++r) room[r] = budget;
+    uint32_t cap_all = 0, n = 0;
+    for (uint32_t i = 0; i < nl; ++i) cap_all += 6 + 2 * (uint32_t)world;      /* per level: <= 6 faces, each cut splits one */
+    PBR_WorkUnit* all = (PBR_WorkUnit*)malloc(sizeof(PBR_WorkUnit) * cap_all);
+    int* owner = (int*)malloc(sizeof(int) * cap_all);
+#define EMIT(L_, F0, F1, R0, R1, RANK) do { PBR_WorkUnit* u_ = &all[n]; \
+        u_->kind = (L_)->irr ? PBR_Unit_Irradiance : PBR_Unit_Prefilter; u_->mip = (L_)->mip; \
+        u_->face0 = (F0); u_->face1 = (F1); u_->row0 = (R0); u_->row1 = (R1); \
+        u_->cost = (double)((F1) - (F0)) * ((R1) - (R0)) * (L_)->raw_row; owner[n++] = (RANK); } while (0)
+    /* 1. whole levels: the pinned copy level, then the cheap ones (largest first; ties -> lowest rank) */
+    for (uint32_t i = 0; i < nl; ++i) {
+        Level* l = &lv[i];
+        double cw = l->w_level;
+        int pinned = !l->irr && l->mip == 0;
+        if (!pinned && cw > budget / 16.0) continue;
+        l->whole = 1;
+        int best = 0;
+        if (!pinned) for (int r = 1; r < world; ++r) if (room[r] > room[best]) best = r;
+        EMIT(l, 0, 6, 0, l->size, best);
+        room[best] -= cw;
+    }
+    /* 2. the rows of the big levels.  Rank 0 first takes a contiguous share from the start of the sequence: the first levels
+     *    have the most output bytes per unit of work (mip 1: 1389 samples per 16-byte texel; it is 3/4 of all bytes that could
+     *    cross xGMI), and what rank 0 computes itself is already where the result is gathered.  The byte-heavy levels that
+     *    remain (>= 5 % of the gathered bytes: mips 1 and 2) are striped over ranks 1..N-1 in proportion to their room, so
+     *    every rank sends about the same number of bytes and the gather runs over all links at once; the compute-heavy rest
+     *    (few bytes) is cut into contiguous shares again, which keeps its dispatches large.  Cuts sit on multiples of 16 rows
+     *    (the kernel's tile height); what a rank leaves over or overdraws is carried to the next one. */
+    double* quota = (double*)calloc((size_t)world, sizeof(double));
+    double* frac = (double*)calloc((size_t)world, sizeof(double));
+    double gathered_bytes = 0.0;
+    for (uint32_t i = 0; i < nl; ++i) if (!lv[i].whole) gathered_bytes += 6.0 * lv[i].size * lv[i].size;
+    int root_full = 0, cr = 1;                               /* cr: rank filling its contiguous share of the rest */
+#define TAKE_ROWS(RANK, AVAIL) do { \
+        left = l->size - row; take = left; cut = 0; \
+        if ((RANK) < world - 1) { \
+            double fit_ = *(AVAIL) / l->w_row[f]; \
+            if (fit_ < (double)left) { \
+                take = fit_ > 0.0 ? (uint32_t)(fit_ + 0.5) : 0; \
+                if (left >= 32) take = (take + 8) & ~15u; \
+                if (take >= left) take = left; else cut = 1; \
+            } \
+        } \
+        if (take > 0) { \
+            /* a whole face following whole faces of the same level on the same rank extends that dispatch */ \
+            if (n > 0 && row == 0 && take == l->size && owner[n - 1] == (RANK) && \
+                all[n - 1].kind == (uint32_t)(l->irr ? PBR_Unit_Irradiance : PBR_Unit_Prefilter) && all[n - 1].mip == l->mip && \
+                all[n - 1].face1 == f && all[n - 1].row0 == 0 && all[n - 1].row1 == l->size) { \
+                all[n - 1].face1 = f + 1; all[n - 1].cost += (double)take * l->raw_row; \
+            } else { \
+                EMIT(l, f, f + 1, row, row + take, (RANK)); \
+            } \
+            if ((AVAIL) != &room[(RANK)]) *(AVAIL) -= (double)take * l->w_row[f]; \
+            room[(RANK)] -= (double)take * l->w_row[f]; \
+            row += take; \
+            if (row == l->size) { row = 0; ++f; } \
+        } } while (0)
+    for (uint32_t i = 0; i < nl; ++i) {
+        Level* l = &lv[i];
+        if (l->whole) continue;
+        uint32_t f = 0, row = 0, left, take;
+        int cut, was_cut_here = 0;
+        if (!root_full) {
+            while (f < 6) {
+                TAKE_ROWS(0, &room[0]);
+                if (cut) break;
+            }
+            if (f == 6) continue;                            /* rank 0 took the whole level and still has room */
+            root_full = 1; was_cut_here = 1;
+            room[1] += room[0];                              /* rank 0's rounding difference */
+        }
+        if (was_cut_here || 6.0 * l->size * l->size >= 0.05 * gathered_bytes) {
+            /* striped over ranks 1..N-1 */
+            double sum = 0.0;
+            for (int r = 1; r < world; ++r) sum += room[r] > 0.0 ? room[r] : 0.0;
+            for (int r = 1; r < world; ++r) frac[r] = sum > 0.0 ? (room[r] > 0.0 ? room[r] : 0.0) / sum : 1.0 / (world - 1);
+            double rem = (double)(l->size - row) * l->w_row[f];
+            for (uint32_t g = f + 1; g < 6; ++g) rem += (double)l->size * l->w_row[g];
+            for (int r = 1; r < world; ++r) quota[r] = rem * frac[r];
+            int r = 1;
+            while (f < 6) {
+                TAKE_ROWS(r, &quota[r]);
+                if (cut && r < world - 1) { quota[r + 1] += quota[r]; ++r; }
+            }
+        } else {
+            /* contiguous shares of what room the ranks have left */
+            while (f < 6) {
+                TAKE_ROWS(cr, &room[cr]);
+                if (cut && cr < world - 1) { room[cr + 1] += room[cr]; ++cr; }
             }
         }
     }
-    free(load); free(all);
+#undef TAKE_ROWS
+    free(quota); free(frac);
+#undef EMIT
+    uint32_t written = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        if (rank < 0 || owner[k] == rank) {
+            if (written < capacity && out) out[written] = all[k];
+            ++written;
+        }
+    }
+    free(room); free(all); free(owner);
     return written;
 }

@@ -202,6 +202,7 @@ PROTOTYPES = {
     "pbrk_host_irradiance_table": (C.c_int, [C.c_int, VP]),
     "pbrk_mip_chain": (C.c_int, [VP, C.c_int, C.c_int, VP]), "pbrk_box_downsample": (C.c_int, [VP, C.c_int, VP, C.c_int, VP]),
     "pbrk_border_build": (C.c_int, [VP, VP, C.c_int, C.c_int, VP]),
+    "pbrk_border_build_range": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "pbrk_debug_sample": (C.c_int, [C.c_int, VP, C.c_int, C.c_int, C.c_int, VP, C.c_int, VP, VP]),
     "pbrk_bloom_pass": (C.c_int, [VP, VP]),
     "pbrk_taa_resolve": (C.c_int, [VP, VP]), "pbrk_final_post_process": (C.c_int, [VP, VP]),
