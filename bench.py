@@ -200,6 +200,20 @@ def main():
     arena = L.GPU_MakeDescriptorArena()
     graph = L.GPU_MakeGraph()
 
+    # the exchange is the same every step: the send/recv descriptors (views of the output memory) are built once
+    gather_ops, staged = [], []
+    if world > 1:
+        if rank == 0:
+            for r in range(1, world):
+                for u in all_units[r]:
+                    dst = unit_slice(*u)
+                    if backend == "nccl":
+                        gather_ops.append(dist.P2POp(dist.irecv, dst, r))
+                    else:
+                        staged.append((r, dst, torch.empty(dst.shape, dtype=dst.dtype)))
+        elif backend == "nccl":
+            gather_ops = [dist.P2POp(dist.isend, unit_slice(*u), 0) for u in all_units[rank]]
+
     def step():
         L.GPU_OpGenerateMipmaps(graph, env_tex)                                   # K2 (+ apron rebuild on first sample)
         L.PBR_RecordUnits(pipes, graph, arena, env_tex, C.byref(maps), my_units, n_my)
@@ -207,25 +221,16 @@ def main():
         L.GPU_GraphWait(graph)
         L.GPU_ResetDescriptorArena(arena)
         if world > 1:                                                             # one grouped RCCL exchange: tiles -> rank 0
-            ops, staged = [], []
-            if rank == 0:
-                for r in range(1, world):
-                    for u in all_units[r]:
-                        dst = unit_slice(*u)
-                        buf = dst if backend == "nccl" else torch.empty(dst.shape, dtype=dst.dtype)
-                        staged.append((dst, buf))
-                        ops.append(dist.P2POp(dist.irecv, buf, r))
-            else:
-                for u in all_units[rank]:
-                    src = unit_slice(*u)
-                    ops.append(dist.P2POp(dist.isend, src if backend == "nccl" else src.cpu(), 0))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
             if backend == "nccl":
+                for w in (dist.batch_isend_irecv(gather_ops) if gather_ops else []):
+                    w.wait()
                 torch.cuda.current_stream().synchronize()      # wait() only orders streams: the step ends when its exchange has landed
             else:
-                for dst, buf in staged:
+                ops = [dist.P2POp(dist.irecv, buf, r) for (r, dst, buf) in staged] if rank == 0 else \
+                      [dist.P2POp(dist.isend, unit_slice(*u).cpu(), 0) for u in all_units[rank]]
+                for w in (dist.batch_isend_irecv(ops) if ops else []):
+                    w.wait()
+                for (r, dst, buf) in staged:
                     dst.copy_(buf)
 
     def sync():
