@@ -1521,9 +1521,16 @@ GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
         Slot* env = tile ? named_slot(op.set, "TEX_ENV_CUBE") : nullptr;
         // a launch of several full-chip rounds (2048 resident workgroups x 256 texels x 8192 samples each) gains nothing from
         // company and keeps its own event timing clean: only smaller ones are overlapped
+        // (a whole level fills the chip by itself from ~1e9 evaluations on; shares of a level -- a rank's tiles -- come in
+        // groups with ragged tails and gain up to the bound above)
         if (tile && out && out->tex) {
-            double texels = (double)(op.face1 - op.face0) * (op.row1 - op.row0) * mip_dim(out->tex->base.width, out->mip);
-            if (texels * dispatch_samples_per_texel(op) >= 2.0e6 * 8192.0) tile = false;
+            uint32_t size = mip_dim(out->tex->base.width, out->mip);
+            double evals = (double)(op.face1 - op.face0) * (op.row1 - op.row0) * size * dispatch_samples_per_texel(op);
+            bool whole = op.face0 == 0 && op.face1 == out->tex->base.layer_count && op.row0 == 0 && op.row1 == size;
+            if (evals >= (whole ? 1.0e9 : 2.0e6 * 8192.0)) tile = false;
+            // fork + join cost ~0.25 ms of cross-stream signalling: whole small levels alone (the tail of a single-GPU job) do not
+            // repay it -- they join a region that shares of a level have opened, but do not open one
+            if (whole && !open) tile = false;
         }
         if (!tile || !out || !env || !out->tex || !env->tex) { close_region(); exec_op(g, op, ev_used); continue; }
         Wr w = {out->tex, out->mip, op.face0, op.face1, op.row0, op.row1};

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(1024) void k_mc_filter_lds(const McArgs p) {
     f3 R = face_texel_dir(face, xc, yc, p.size);
     f3 T = tangent_of(R);
     f3 B = cross3(T, R);
-    const float nf = (float)p.n_src;
+    const float nf = (float)p.n_src, nbf = (float)nb;
     const float off = 0.5f * nf + 0.5f;
     const float4* __restrict__ tab = p.tab;
     __syncthreads();
@@ -208,11 +208,16 @@ __global__ __launch_bounds__(1024) void k_mc_filter_lds(const McArgs p) {
         L.x = fmaf(ex, B.x, fmaf(ey, T.x, ez * R.x));
         L.y = fmaf(ex, B.y, fmaf(ey, T.y, ez * R.y));
         L.z = fmaf(ex, B.z, fmaf(ey, T.z, ez * R.z));
-        int f; float u, v;
-        cube_project(L, nf, off, &f, &u, &v);
+        float fid = __builtin_amdgcn_cubeid(L.x, L.y, L.z);
+        float sc = __builtin_amdgcn_cubesc(L.x, L.y, L.z);
+        float tc = __builtin_amdgcn_cubetc(L.x, L.y, L.z);
+        float h = __builtin_amdgcn_rcpf(fabsf(__builtin_amdgcn_cubema(L.x, L.y, L.z))) * nf;
+        float u = fmaf(sc, h, off), v = fmaf(tc, h, off);
         float a = __builtin_amdgcn_fractf(u), b = __builtin_amdgcn_fractf(v);
-        int i0 = min((int)u, p.n_src), j0 = min((int)v, p.n_src);          // LDS reads are not range-checked: keep taps in the level
-        const float4* wp = lvl + ((min(f, 5) * nb + j0) * nb + i0);
+        // texel index in exact fp32 (the level has at most 6*34*34 texels): full-rate FMAs instead of conversions and quarter-rate
+        // integer multiplies; LDS reads are not range-checked, so the taps are kept inside the level as before
+        float i0 = fminf(floorf(u), nf), j0 = fminf(floorf(v), nf);
+        const float4* wp = lvl + (int)fmaf(fmaf(fminf(fid, 5.0f), nbf, j0), nbf, i0);
         float4 q00 = wp[0], q10 = wp[1], q01 = wp[nb], q11 = wp[nb + 1];
         float cr = lerp_fma(lerp_fma(q00.x, q10.x, a), lerp_fma(q01.x, q11.x, a), b);
         float cg = lerp_fma(lerp_fma(q00.y, q10.y, a), lerp_fma(q01.y, q11.y, a), b);

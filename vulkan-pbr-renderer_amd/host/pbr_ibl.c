@@ -298,6 +298,7 @@ uint32_t PBR_PartitionIBL(uint32_t specular_size, uint32_t min_size, uint32_t ir
         EMIT(l, 0, 6, 0, l->size, best);
         room[best] -= cw;
     }
+    const uint32_t n_whole = n;
     /* 2. the rows of the big levels.  Rank 0 first takes a contiguous share from the start of the sequence: the first levels
      *    have the most output bytes per unit of work (mip 1: 1389 samples per 16-byte texel; it is 3/4 of all bytes that could
      *    cross xGMI), and what rank 0 computes itself is already where the result is gathered.  The byte-heavy levels that
@@ -372,11 +373,20 @@ uint32_t PBR_PartitionIBL(uint32_t specular_size, uint32_t min_size, uint32_t ir
 #undef TAKE_ROWS
     free(quota); free(frac);
 #undef EMIT
+    /* A rank's list: its shares of the big levels, smallest level first, then the whole small levels.  The backend overlaps
+     * these dispatches on side streams; the kernels of the smaller levels use 1024-thread workgroups with the source level in
+     * LDS, which only find a CU with 16 free wave slots while the chip is not yet full of the 4-wave workgroups of the big
+     * levels -- started last they would wait for those to drain and run alone at the end (measured: 19.2 instead of 17.8 ms
+     * for a share holding two such dispatches).  The whole small levels are latency-bound and hide anywhere. */
     uint32_t written = 0;
-    for (uint32_t k = 0; k < n; ++k) {
-        if (rank < 0 || owner[k] == rank) {
-            if (written < capacity && out) out[written] = all[k];
-            ++written;
+    for (int m = 64; m >= -1; --m) {
+        /* m = 64: irradiance shares, 63..0: prefilter shares by descending mip, -1: the whole levels of step 1 */
+        for (uint32_t k = m < 0 ? 0 : n_whole; k < (m < 0 ? n_whole : n); ++k) {
+            if (m >= 0 && (all[k].kind == PBR_Unit_Irradiance ? 64 : (int)all[k].mip) != m) continue;
+            if (rank < 0 || owner[k] == rank) {
+                if (written < capacity && out) out[written] = all[k];
+                ++written;
+            }
         }
     }
     free(room); free(all); free(owner);
