@@ -15,6 +15,14 @@ template <int OP> __global__ void k(float* out, float a, float b) {
         if (OP == 5) { p.x = fmaf(p.x, q.x, q.y); p.y = fmaf(p.y, q.x, q.y); q.x = fmaf(q.x, p.x, p.y); q.y = fmaf(q.y, p.x, p.y); }   // pk candidates
         if (OP == 6) { x = floorf(x); y = floorf(y); z = floorf(z); w = floorf(w); }
         if (OP == 7) { int ix = __builtin_amdgcn_readlane(__float_as_int(x), i & 63); x = __int_as_float(ix) + y; int iy = __builtin_amdgcn_readlane(__float_as_int(y), (i + 1) & 63); y = __int_as_float(iy) + z; z += w; w += x; }
+        if (OP >= 8) {   // integer multiplies (tap addresses): 32-bit, 32-bit multiply-add, 24-bit, 24-bit multiply-add
+            int ix = __float_as_int(x), iy = __float_as_int(y), iz = __float_as_int(z), iw = __float_as_int(w);
+            if (OP == 8) { ix = ix * iy; iy = iy * iz; iz = iz * iw; iw = iw * ix; }
+            if (OP == 9) { ix = ix * iy + iz; iy = iy * iz + iw; iz = iz * iw + ix; iw = iw * ix + iy; }
+            if (OP == 10) { ix = __mul24(ix, iy); iy = __mul24(iy, iz); iz = __mul24(iz, iw); iw = __mul24(iw, ix); }
+            if (OP == 11) { ix = __mul24(ix, iy) + iz; iy = __mul24(iy, iz) + iw; iz = __mul24(iz, iw) + ix; iw = __mul24(iw, ix) + iy; }
+            x = __int_as_float(ix); y = __int_as_float(iy); z = __int_as_float(iz); w = __int_as_float(iw);
+        }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x + y + z + w + p.x + p.y + q.x + q.y;
 }
@@ -35,5 +43,6 @@ template <int OP> void run(const char* name, int ops_per_iter) {
 }
 int main() {
     run<0>("fma", 4); run<1>("cube", 4); run<2>("rcp", 4); run<3>("fract", 4); run<4>("cvt2", 8); run<5>("fma_vec2", 4); run<6>("floor", 4); run<7>("readlane", 6);
+    run<8>("mul_lo", 4); run<9>("mul_add32", 4); run<10>("mul_i24", 4); run<11>("mad_i24", 4);
     return 0;
 }

@@ -64,8 +64,8 @@ __device__ __forceinline__ f3 sample_bordered(__amdgpu_buffer_rsrc_t rs, f3 L, f
     f3 t00, t10, t01, t11;
     if (CELLS) {
         // Cell byte offset in fp32: cells exist for n <= 512 only, so face*nc + j0, the cell index (< 6*513^2 < 2^24) and
-        // 48*cell (= 16 * an integer < 2^24) are all exact -- six full-rate instructions instead of three conversions and
-        // three quarter-rate integer multiplies (this loop is as VALU-bound as it is L1-bound).
+        // 48*cell (= 16 * an integer < 2^24) are all exact -- six FMA-rate instructions instead of three conversions and three
+        // integer multiplies (v_mul_lo_u32 / v_mad_u64_u32 issue at 1.45x / 1.7x the cost of an FMA here, tools/ubench_valu.hip).
         float ncf = (float)(nb - 1);                             // n + 1 tap positions per edge
         float cellf = fmaf(fmaf(fid, ncf, floorf(v)), ncf, floorf(u));
         taps_cells(rs, (int)(cellf * 48.0f), t00, t10, t01, t11);
@@ -214,8 +214,8 @@ __global__ __launch_bounds__(1024) void k_mc_filter_lds(const McArgs p) {
         float h = __builtin_amdgcn_rcpf(fabsf(__builtin_amdgcn_cubema(L.x, L.y, L.z))) * nf;
         float u = fmaf(sc, h, off), v = fmaf(tc, h, off);
         float a = __builtin_amdgcn_fractf(u), b = __builtin_amdgcn_fractf(v);
-        // texel index in exact fp32 (the level has at most 6*34*34 texels): full-rate FMAs instead of conversions and quarter-rate
-        // integer multiplies; LDS reads are not range-checked, so the taps are kept inside the level as before
+        // texel index in exact fp32 (the level has at most 6*34*34 texels): FMAs instead of conversions, integer clamps and integer
+        // multiplies (1.45x-1.7x an FMA each); LDS reads are not range-checked, so the taps are kept inside the level as before
         float i0 = fminf(floorf(u), nf), j0 = fminf(floorf(v), nf);
         const float4* wp = lvl + (int)fmaf(fmaf(fminf(fid, 5.0f), nbf, j0), nbf, i0);
         float4 q00 = wp[0], q10 = wp[1], q01 = wp[nb], q11 = wp[nb + 1];
