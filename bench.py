@@ -389,6 +389,18 @@ def main():
             L.GPU_GraphSubmit(graph); L.GPU_GraphWait(graph); L.GPU_ResetDescriptorArena(arena)
             extra["check_gather_equals_single_gpu"] = bool(torch.equal(gathered, spec_mem))
 
+    # SURVEY 8(d) headline rates of the whole job (all ranks): Monte-Carlo texels only, sample evaluations, algorithmic bytes
+    mc_texels = sum(6 * max(1, spec_size >> m) ** 2 for m in range(1, n_mips)) + 6 * irr_size * irr_size
+    sample_evals = sum(6.0 * max(1, spec_size >> m) ** 2 * nonzero_weight_count(L, 8192, ref_roughness(m)) for m in range(1, n_mips)) \
+        + 6.0 * irr_size * irr_size * 1024
+    alg_bytes = 16.0 * total_texels + 16.0 * 6 * (W // 2) ** 2 + 160.0 * W * W        # outputs + copy-level source + mip chain
+    rates = {"mtexels_per_s_all_mips": value, "mtexels_per_s_mc_mips": mc_texels * args.steps / elapsed / 1e6,
+             "msamples_per_s": sample_evals * args.steps / elapsed / 1e6,
+             "valu_fraction_of_fp32_peak": sample_evals * FLOP_PER_SAMPLE * args.steps / elapsed / 1e12 / (PEAK_FP32_TFLOPS * world),
+             "hbm_gbs_by_algorithmic_bytes": alg_bytes * args.steps / elapsed / 1e9,
+             "hbm_fraction_by_algorithmic_bytes": alg_bytes * args.steps / elapsed / 1e9 / (PEAK_HBM_GBS * world),
+             "note": "the job is compute-bound by construction (up to 8192 sample evaluations per 16-byte texel): the HBM fraction is tiny"}
+
     if rank == 0:
         out = {
             "metric": "IBL-prefilter Mtexels/s (specular prefilter all mips + irradiance; PBR-shaded Mpixels/s under extra.shade_c5 / extra.shade)",
@@ -396,9 +408,9 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "env": f"procedural HDR cube {W}^2 x6 RGBA32F (seed {seed:#x}, RGBE round-tripped)",
-                       "texels_per_step": total_texels,
+                       "texels_per_step": total_texels, "sample_evaluations_per_step": sample_evals,
                        "parallelism": "single GPU" if world == 1 else f"{world} ranks, weighted linear partition of output rows (3-8 dispatches per rank), 1 grouped RCCL send/recv gather per step"},
-            "roofline": roofline, "roofline_hbm": roofline_hbm, "kernels": kernels[:12],
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "rates": rates, "kernels": kernels[:12],
             "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(out))
