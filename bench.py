@@ -214,12 +214,17 @@ def main():
         elif backend == "nccl":
             gather_ops = [dist.P2POp(dist.isend, unit_slice(*u), 0) for u in all_units[rank]]
 
+    phase = {"compute": 0.0, "exchange": 0.0}           # host-clock split of a step on this rank (reported for N > 1)
+
     def step():
+        t_a = time.perf_counter()
         L.GPU_OpGenerateMipmaps(graph, env_tex)                                   # K2 (+ apron rebuild on first sample)
         L.PBR_RecordUnits(pipes, graph, arena, env_tex, C.byref(maps), my_units, n_my)
         L.GPU_GraphSubmit(graph)
         L.GPU_GraphWait(graph)
         L.GPU_ResetDescriptorArena(arena)
+        t_b = time.perf_counter()
+        phase["compute"] += t_b - t_a
         if world > 1:                                                             # one grouped RCCL exchange: tiles -> rank 0
             if backend == "nccl":
                 for w in (dist.batch_isend_irecv(gather_ops) if gather_ops else []):
@@ -232,6 +237,7 @@ def main():
                     w.wait()
                 for (r, dst, buf) in staged:
                     dst.copy_(buf)
+            phase["exchange"] += time.perf_counter() - t_b
 
     def sync():
         if world > 1:
@@ -242,6 +248,7 @@ def main():
     for _ in range(args.warmup):
         step()
     op_ms = {}
+    phase["compute"] = phase["exchange"] = 0.0
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -255,6 +262,15 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    step_split = None
+    if world > 1:       # per-rank compute time and (on rank 0: waiting for the slowest sender + the transfer itself) exchange time
+        pt = torch.tensor([phase["compute"], phase["exchange"]], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        gathered = [torch.zeros_like(pt) for _ in range(world)]
+        dist.all_gather(gathered, pt)
+        step_split = {"compute_ms_per_step_by_rank": [float(g[0]) / args.steps * 1e3 for g in gathered],
+                      "exchange_ms_per_step_by_rank": [float(g[1]) / args.steps * 1e3 for g in gathered],
+                      "bytes_sent_by_rank": [0] + [int(sum(unit_slice(*u).numel() * 4 for u in all_units[r])) for r in range(1, world)]}
 
     total_texels = sum(6 * max(1, spec_size >> m) ** 2 for m in range(n_mips)) + 6 * irr_size * irr_size
     ms_per_step = elapsed / args.steps * 1e3
@@ -410,7 +426,7 @@ def main():
             "config": {"workload": desc, "env": f"procedural HDR cube {W}^2 x6 RGBA32F (seed {seed:#x}, RGBE round-tripped)",
                        "texels_per_step": total_texels, "sample_evaluations_per_step": sample_evals,
                        "parallelism": "single GPU" if world == 1 else f"{world} ranks, weighted linear partition of output rows (3-8 dispatches per rank), 1 grouped RCCL send/recv gather per step"},
-            "roofline": roofline, "roofline_hbm": roofline_hbm, "rates": rates, "kernels": kernels[:12],
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "rates": rates, "step_split": step_split, "kernels": kernels[:12],
             "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(out))
