@@ -1,0 +1,323 @@
+// k_mc_region.hip -- K4b / K3 for source levels too big for LDS as a whole: taps served from LDS-staged REGIONS.
+//
+// Same sum as k_mc.hip (gen_prefiltered_env_map.glsl:115-146, gen_irradiance_map.glsl:81-97):
+//   out.rgb(texel) = ( sum_i w_i * bilinear(src, frame(texel) * l_i) ) / divisor
+//
+// Why: the direct kernel moves 48 B per (texel, sample) through the vector L1 (64 B/clk/CU): 48 clk per wave-sample per
+// CU whatever the hit rate, above its ~40 clk of VALU work.  LDS delivers 256 B/clk/CU, but only levels up to 32^2 fit as a
+// whole.  Here the bordered source level is cut into regions of at most 66 x 66 texels (70 KB: a whole face at n = 64, a
+// quarter face at n = 128), and a 1024-thread workgroup (16 x 16 output texels x 4 slices of the sample table, two workgroups
+// per CU) walks the regions one after the other:
+//   1. binning (once per tile): every sample direction is pushed through the tile-centre frame; a rigorous bound on how far
+//      any texel of the tile can move it (|M_texel - M_centre|_F) yields the regions it can reach; one bit per (region,
+//      sample) in LDS.  ~1 % of the work.
+//   2. per flagged region: stage it in LDS, then every wave runs the flagged samples of its slice.  The face is known per
+//      pass, so the cube projection is a static signed permutation folded into the frame (no v_cube*), each lane tests
+//      exactly whether ITS direction falls into this region's cells (the hardware's tie rule: z >= y >= x), and lanes that
+//      do not are masked (weight 0): they meet the sample again in the pass of their own region.
+//   3. every lane counts the samples it has accumulated.  A count short of the slice's sample count would mean the bound of
+//      step 1 missed a region; the wave then recomputes its slice with direct loads (never observed; counter in stats[0]).
+// Each (texel, sample) pair is accumulated exactly once, in an order (region, then sample index) that depends on the texel
+// only, not on the tile: a row-sharded dispatch equals a full one bit for bit.
+#include "pbr_device.h"
+#include "pbr_kernels.h"
+#include "k_mc_internal.h"
+
+#include <stdlib.h>
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+// The sample table is read-only for the whole launch: a pointer into the constant address space makes every wave-uniform
+// read of it a scalar load (behind the kernel's barriers / LDS atomics the compiler no longer proves that for a global pointer
+// and falls back to 64-lane vector loads of one address).
+typedef const __attribute__((address_space(4))) v4f* ctab_t;
+
+#define REG_S 4                 // sample-table slices per workgroup (waves 4s..4s+3 own slice s)
+#define REG_TX 256              // output texels per workgroup (16 x 16)
+
+struct RegArgs {
+    McArgs a;
+    int G;                      // regions per face edge
+    int RC;                     // tap positions (cells) per region edge; the last region of a row may hold fewer
+    int NR;                     // 6 * G * G
+    int NW;                     // mask words per region = ceil(n_tab / 32)
+    int expect[REG_S];          // samples per slice
+    unsigned long long* stats;  // optional: [0] += healed wave-slices, [1] += all wave-slices
+};
+
+// direction -> (sc, tc, ma) of face f: the table of v_cubesc / v_cubetc / v_cubema (gen_prefiltered_env_map.glsl:12-23)
+__device__ __forceinline__ void face_coords(int f, float x, float y, float z, float& sc, float& tc, float& ma) {
+    switch (f) {
+    case 0: sc = -z; tc = -y; ma = x; break;
+    case 1: sc = z; tc = -y; ma = -x; break;
+    case 2: sc = x; tc = z; ma = y; break;
+    case 3: sc = x; tc = -z; ma = -y; break;
+    case 4: sc = x; tc = -y; ma = z; break;
+    default: sc = -x; tc = -y; ma = -z; break;
+    }
+}
+
+// One pass over the flagged samples of this wave's slice for the staged region.
+// CLS = major axis of the region's face (0: x, 1: y, 2: z): the hardware's tie rule (z >= y >= x) in two comparisons.
+template <int RS, bool SUB, int CLS>
+__device__ __forceinline__ void region_pass(const float4* __restrict__ region, const unsigned* __restrict__ mwords, int NW, int s,
+                                            ctab_t tab, f3 Pb, f3 Pt, f3 Pr, float half_n, float off,
+                                            int ox, int oy, unsigned rcx, unsigned rcy,
+                                            float& ar, float& ag, float& ab, unsigned& cnt) {
+    for (int w = s; w < NW; w += REG_S) {
+        unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)mwords[w]);
+        while (m) {
+            const int i = (w << 5) + __builtin_ctz(m);
+            m &= m - 1u;
+            const v4f e = tab[i];
+            // (sc, tc, ma) = permuted frame * local direction, same FMA order as the direct kernel's L
+            const float sc = fmaf(e.x, Pb.x, fmaf(e.y, Pt.x, e.z * Pr.x));
+            const float tc = fmaf(e.x, Pb.y, fmaf(e.y, Pt.y, e.z * Pr.y));
+            const float ma = fmaf(e.x, Pb.z, fmaf(e.y, Pt.z, e.z * Pr.z));
+            bool in;
+            if (CLS == 0) in = (ma > fabsf(sc)) && (ma > fabsf(tc));
+            else if (CLS == 1) in = (ma >= fabsf(sc)) && (ma > fabsf(tc));
+            else in = (ma >= fabsf(sc)) && (ma >= fabsf(tc));
+            // Lanes whose direction is not on this face (or, SUB, not in this region's cells) sit the sample out under the exec
+            // mask: no selects, and a wave none of whose lanes is in skips the rest (s_cbranch_execz).
+            if (in) {
+                const float h = __builtin_amdgcn_rcpf(ma) * half_n;
+                const float u = fmaf(sc, h, off), v = fmaf(tc, h, off);               // bordered tap coordinates, [0.5, n + 0.5]
+                int il = (int)u, jl = (int)v;
+                bool in2 = true;
+                if (SUB) {
+                    il -= ox; jl -= oy;
+                    in2 = ((unsigned)il < rcx) && ((unsigned)jl < rcy);
+                }
+                if (in2) {
+                    const float a = __builtin_amdgcn_fractf(u), b = __builtin_amdgcn_fractf(v);
+                    cnt += 1u;
+                    // whole 16-byte texels: ds_read_b128 runs at 256 B/clk/CU, the 12-byte form the compiler would pick at 96 (the
+                    // empty asm keeps the fourth component alive)
+                    const v4f* tp = (const v4f*)(region + (__mul24(jl, RS) + il));
+                    v4f q00 = tp[0], q10 = tp[1], q01 = tp[RS], q11 = tp[RS + 1];
+                    asm("" : "+v"(q00)); asm("" : "+v"(q10)); asm("" : "+v"(q01)); asm("" : "+v"(q11));
+                    // weights of the four taps with the sample weight folded in
+                    const float wgt = e.w;
+                    const float wa = wgt * a;
+                    const float w11 = wa * b;
+                    const float w10 = wa - w11;
+                    const float wb = wgt * b;
+                    const float w01 = wb - w11;
+                    const float w00 = (wgt - wa) - w01;
+                    ar = fmaf(w11, q11.x, fmaf(w01, q01.x, fmaf(w10, q10.x, fmaf(w00, q00.x, ar))));
+                    ag = fmaf(w11, q11.y, fmaf(w01, q01.y, fmaf(w10, q10.y, fmaf(w00, q00.y, ag))));
+                    ab = fmaf(w11, q11.z, fmaf(w01, q01.z, fmaf(w10, q10.z, fmaf(w00, q00.z, ab))));
+                }
+            }
+        }
+    }
+}
+
+template <int RS, bool SUB>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mc_region(const RegArgs q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
+    float4* region = (float4*)smem_r;
+    unsigned* masks = (unsigned*)(smem_r + RS * RS * 16);
+    unsigned* any = masks + q.NR * q.NW;
+    unsigned* dmax = any + q.NR;
+    const McArgs& p = q.a;
+    const int tid = threadIdx.x;
+    const int s = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int t = tid & 255;
+
+    unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int face = p.face0 + (int)(tile / (unsigned)p.tiles_per_face);
+    const int tf = (int)(tile % (unsigned)p.tiles_per_face);
+    const int ty = tf / p.tiles_x, tx = tf % p.tiles_x;
+    const int x = tx * 16 + (t & 15);
+    const int y = p.y0 + ty * 16 + (t >> 4);
+    const bool valid = (x < p.size) && (y < p.y0 + p.rows);
+    const int xc = min(x, p.size - 1), yc = min(y, p.y0 + p.rows - 1);
+
+    const f3 R = face_texel_dir(face, xc, yc, p.size);
+    const f3 T = tangent_of(R);
+    const f3 B = cross3(T, R);
+    // tile-centre frame (evaluated redundantly per lane: wave-uniform values)
+    const f3 Rc = face_texel_dir(face, min(tx * 16 + 8, p.size - 1), min(p.y0 + ty * 16 + 8, p.y0 + p.rows - 1), p.size);
+    const f3 Tc = tangent_of(Rc);
+    const f3 Bc = cross3(Tc, Rc);
+
+    const int n = p.n_src, nb = n + 2;
+    const float nf = (float)n;
+    const float half_n = 0.5f * nf;
+    const float off = 0.5f * nf + 0.5f;
+    ctab_t tab = (ctab_t)(unsigned long long)p.tab;
+    const int NW = q.NW, NR = q.NR, G = q.G, RC = q.RC;
+
+    // ---- 1. binning ----
+    for (int k = tid; k < NR * NW + NR + 1; k += 1024) masks[k] = 0u;
+    __syncthreads();
+    {
+        f3 dR = sub3(R, Rc), dT = sub3(T, Tc), dB = sub3(B, Bc);
+        float d2 = dot3(dR, dR) + dot3(dT, dT) + dot3(dB, dB);
+        atomicMax(dmax, __float_as_uint(sqrtf(d2)));                 // non-negative floats order like their bit patterns
+    }
+    __syncthreads();
+    // |L_texel - L_centre| <= |M_texel - M_centre|_F for a unit local direction; inflated for the rounding of both evaluations
+    const float delta = __uint_as_float(*dmax) * 1.0001f + 2e-6f;
+    for (int i = tid; i < p.n_tab; i += 1024) {
+        const v4f e = tab[i];
+        const float Lx = fmaf(e.x, Bc.x, fmaf(e.y, Tc.x, e.z * Rc.x));
+        const float Ly = fmaf(e.x, Bc.y, fmaf(e.y, Tc.y, e.z * Rc.y));
+        const float Lz = fmaf(e.x, Bc.z, fmaf(e.y, Tc.z, e.z * Rc.z));
+        const unsigned bit = 1u << (i & 31);
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            float sc, tc, ma;
+            face_coords(f, Lx, Ly, Lz, sc, tc, ma);
+            // some direction within delta (per component) of L can have face f only if ma + delta >= |sc| - delta (same for tc)
+            if (!(ma + 2.0f * delta >= fabsf(sc)) || !(ma + 2.0f * delta >= fabsf(tc))) continue;
+            int lo_u = 0, hi_u = n, lo_v = 0, hi_v = n;
+            const float mlo = ma - delta;
+            if (mlo > 0.2f) {
+                // |sc'/ma' - sc/ma| <= delta (1 + |sc/ma|) / (ma - delta); + 0.05 texel for the rounding of rcp / fma
+                const float rm = 1.0f / ma, rl = 1.0f / mlo;
+                const float ru = sc * rm, rv = tc * rm;
+                const float mu = delta * (1.0f + fabsf(ru)) * rl * half_n + 0.05f;
+                const float mv = delta * (1.0f + fabsf(rv)) * rl * half_n + 0.05f;
+                const float uc = fmaf(ru, half_n, off), vc = fmaf(rv, half_n, off);
+                const float ul = floorf(uc - mu), uh = floorf(uc + mu), vl = floorf(vc - mv), vh = floorf(vc + mv);
+                if (uh < 0.0f || ul > nf || vh < 0.0f || vl > nf) continue;      // cannot be on this face at all
+                lo_u = (int)fmaxf(ul, 0.0f); hi_u = (int)fminf(uh, nf);
+                lo_v = (int)fmaxf(vl, 0.0f); hi_v = (int)fminf(vh, nf);
+            }
+            const int gx0 = lo_u / RC, gx1 = hi_u / RC, gy0 = lo_v / RC, gy1 = hi_v / RC;
+            for (int gy = gy0; gy <= gy1; ++gy)
+                for (int gx = gx0; gx <= gx1; ++gx) {
+                    const int r = (f * G + gy) * G + gx;
+                    atomicOr(&masks[r * NW + (i >> 5)], bit);
+                    any[r] = 1u;
+                }
+        }
+    }
+
+    // ---- 2. region passes ----
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    unsigned cnt = 0;
+    for (int r = 0; r < NR; ++r) {
+        __syncthreads();                                           // binning done / readers of the previous region done
+        if (any[r] == 0u) continue;                                // workgroup-uniform
+        const int f = r / (G * G);
+        const int gy = (r / G) % G, gx = r % G;
+        const int ox = gx * RC, oy = gy * RC;
+        const int rcx = min(RC, n + 1 - ox), rcy = min(RC, n + 1 - oy);      // cells of this region; texels: one more
+        const float4* __restrict__ fsrc = p.src + ((size_t)f * nb + oy) * nb + ox;
+        for (int k = tid; k < RS * RS; k += 1024) {
+            const int ry = k / RS, rx = k - ry * RS;
+            if (rx <= rcx && ry <= rcy) region[k] = fsrc[ry * nb + rx];
+        }
+        __syncthreads();
+        // signed permutation of the frame for this face: rows give (sc, tc, ma) directly
+        f3 Pb, Pt, Pr;
+        face_coords(f, B.x, B.y, B.z, Pb.x, Pb.y, Pb.z);
+        face_coords(f, T.x, T.y, T.z, Pt.x, Pt.y, Pt.z);
+        face_coords(f, R.x, R.y, R.z, Pr.x, Pr.y, Pr.z);
+        const unsigned* mw = masks + r * NW;
+        switch (f >> 1) {
+        case 0: region_pass<RS, SUB, 0>(region, mw, NW, s, tab, Pb, Pt, Pr, half_n, off, ox, oy, (unsigned)rcx, (unsigned)rcy, ar, ag, ab, cnt); break;
+        case 1: region_pass<RS, SUB, 1>(region, mw, NW, s, tab, Pb, Pt, Pr, half_n, off, ox, oy, (unsigned)rcx, (unsigned)rcy, ar, ag, ab, cnt); break;
+        default: region_pass<RS, SUB, 2>(region, mw, NW, s, tab, Pb, Pt, Pr, half_n, off, ox, oy, (unsigned)rcx, (unsigned)rcy, ar, ag, ab, cnt); break;
+        }
+    }
+
+    // ---- 3. completeness check; a wave that missed a sample recomputes its slice with direct loads ----
+    const unsigned expect = (unsigned)(s == 0 ? q.expect[0] : (s == 1 ? q.expect[1] : (s == 2 ? q.expect[2] : q.expect[3])));
+    const bool healed = __builtin_amdgcn_ballot_w64(cnt != expect) != 0;
+    if (healed) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)p.src_bytes, 0x00020000);
+        ar = 0.0f; ag = 0.0f; ab = 0.0f;
+        for (int w = s; w < NW; w += REG_S) {
+            const int i1 = min((w << 5) + 32, p.n_tab);
+            for (int i = w << 5; i < i1; ++i) {
+                const v4f e = tab[i];
+                f3 L;
+                L.x = fmaf(e.x, B.x, fmaf(e.y, T.x, e.z * R.x));
+                L.y = fmaf(e.x, B.y, fmaf(e.y, T.y, e.z * R.y));
+                L.z = fmaf(e.x, B.z, fmaf(e.y, T.z, e.z * R.z));
+                f3 c = sample_bordered<false>(rs, L, nf, off, nb, nb * 16);
+                ar = fmaf(e.w, c.x, ar); ag = fmaf(e.w, c.y, ag); ab = fmaf(e.w, c.z, ab);
+            }
+        }
+    }
+    if (q.stats && (tid & 63) == 0) {
+        if (healed) atomicAdd(&q.stats[0], 1ull);
+        atomicAdd(&q.stats[1], 1ull);
+    }
+
+    // ---- 4. combine the slices (fixed tree) and store ----
+    __syncthreads();                                               // everybody is done with the staged region
+    float* red = (float*)smem_r;
+    red[(s * REG_TX + t) * 3 + 0] = ar;
+    red[(s * REG_TX + t) * 3 + 1] = ag;
+    red[(s * REG_TX + t) * 3 + 2] = ab;
+    __syncthreads();
+    for (int stride = REG_S / 2; stride >= 1; stride >>= 1) {
+        if (s < stride) {
+            const int a2 = (s * REG_TX + t) * 3, b2 = ((s + stride) * REG_TX + t) * 3;
+            red[a2 + 0] += red[b2 + 0];
+            red[a2 + 1] += red[b2 + 1];
+            red[a2 + 2] += red[b2 + 2];
+        }
+        __syncthreads();
+    }
+    if (valid && s == 0) {
+        float4 o;
+        o.x = red[t * 3 + 0] / p.divisor; o.y = red[t * 3 + 1] / p.divisor; o.z = red[t * 3 + 2] / p.divisor; o.w = p.alpha;
+        p.out[((size_t)face * p.size + y) * p.size + x] = o;
+    }
+}
+
+static unsigned long long* g_reg_stats = nullptr;      // device counters, enabled by PBR_MC_STATS=1
+
+extern "C" int pbrk_mc_region_stats(unsigned long long* out2, int reset) {
+    if (!g_reg_stats || !out2) return PBRK_E_ARG;
+    if (hipMemcpy(out2, g_reg_stats, 16, hipMemcpyDeviceToHost) != hipSuccess) return PBRK_E_LAUNCH;
+    if (reset && hipMemset(g_reg_stats, 0, 16) != hipSuccess) return PBRK_E_LAUNCH;
+    return PBRK_OK;
+}
+
+template <int RS, bool SUB>
+static void launch_region_t(const RegArgs& q, unsigned grid, size_t lds, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_mc_region<RS, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL((k_mc_region<RS, SUB>), dim3(grid), dim3(1024), lds, st, q);
+}
+
+bool launch_mc_region(McArgs a, int nfaces, hipStream_t st) {
+    static int mode = -1, stats_on = -1;
+    if (mode < 0) { const char* e = getenv("PBR_MC_REGION"); mode = e ? atoi(e) : 1; }
+    if (!mode) return false;
+    // shape conditions (level only): source too big for LDS as a whole, enough 16x16 tiles to fill the chip twice over
+    if (a.n_src < 24 || a.size < 256 || a.n_tab < 1 || a.n_tab > 8192) return false;
+    RegArgs q;
+    q.a = a;
+    int RS;
+    if (a.n_src <= 32) { RS = 34; q.G = 1; q.RC = a.n_src + 1; }
+    else if (a.n_src <= 64) { RS = 66; q.G = 1; q.RC = a.n_src + 1; }
+    else { RS = 66; q.RC = 65; q.G = (a.n_src + 1 + 64) / 65; }
+    q.NR = 6 * q.G * q.G;
+    q.NW = (a.n_tab + 31) / 32;
+    size_t lds = (size_t)RS * RS * 16 + ((size_t)q.NR * q.NW + q.NR + 4) * 4;
+    if (lds < (size_t)REG_S * REG_TX * 3 * 4) lds = (size_t)REG_S * REG_TX * 3 * 4;
+    if (lds > 80 * 1024) return false;                             // two workgroups per CU or not at all
+    for (int s = 0; s < REG_S; ++s) q.expect[s] = 0;
+    for (int w = 0; w < q.NW; ++w) { int c = a.n_tab - w * 32; q.expect[w % REG_S] += c > 32 ? 32 : c; }
+    if (stats_on < 0) {
+        const char* e = getenv("PBR_MC_STATS"); stats_on = e ? atoi(e) : 0;
+        if (stats_on) { if (hipMalloc(&g_reg_stats, 16) != hipSuccess) g_reg_stats = nullptr; else (void)hipMemset(g_reg_stats, 0, 16); }
+    }
+    q.stats = g_reg_stats;
+    q.a.tiles_x = (a.size + 15) / 16;
+    int tiles_y = (a.rows + 15) / 16;
+    q.a.tiles_per_face = q.a.tiles_x * tiles_y;
+    unsigned grid = (unsigned)(q.a.tiles_per_face * nfaces);
+    if (RS == 34) launch_region_t<34, false>(q, grid, lds, st);
+    else if (q.G == 1) launch_region_t<66, false>(q, grid, lds, st);
+    else launch_region_t<66, true>(q, grid, lds, st);
+    return true;
+}
