@@ -15,8 +15,9 @@
 //      pass, so the cube projection is a static signed permutation folded into the frame (no v_cube*), each lane tests
 //      exactly whether ITS direction falls into this region's cells (the hardware's tie rule: z >= y >= x), and lanes that
 //      do not are masked (weight 0): they meet the sample again in the pass of their own region.
-//   3. every lane counts the samples it has accumulated.  A count short of the slice's sample count would mean the bound of
-//      step 1 missed a region; the wave then recomputes its slice with direct loads (never observed; counter in stats[0]).
+//   3. every wave counts the (lane, sample) pairs it has accumulated (scalar popcount of the exec mask).  A total short of
+//      64 x the slice's sample count would mean the bound of step 1 missed a region; the wave then recomputes its slice with
+//      direct loads (never observed; counter in stats[0]).
 // Each (texel, sample) pair is accumulated exactly once, in an order (region, then sample index) that depends on the texel
 // only, not on the tile: a row-sharded dispatch equals a full one bit for bit.
 #include "pbr_device.h"
@@ -30,6 +31,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // read of it a scalar load (behind the kernel's barriers / LDS atomics the compiler no longer proves that for a global pointer
 // and falls back to 64-lane vector loads of one address).
 typedef const __attribute__((address_space(4))) v4f* ctab_t;
+typedef const __attribute__((address_space(3))) v4f* lds_v4f_p;
 
 #define REG_S 4                 // sample-table slices per workgroup (waves 4s..4s+3 own slice s)
 #define REG_TX 256              // output texels per workgroup (16 x 16)
@@ -59,9 +61,9 @@ __device__ __forceinline__ void face_coords(int f, float x, float y, float z, fl
 // One pass over the flagged samples of this wave's slice for the staged region.
 // CLS = major axis of the region's face (0: x, 1: y, 2: z): the hardware's tie rule (z >= y >= x) in two comparisons.
 template <int RS, bool SUB, int CLS>
-__device__ __forceinline__ void region_pass(const float4* __restrict__ region, const unsigned* __restrict__ mwords, int NW, int s,
+__device__ __forceinline__ void region_pass(unsigned lds_base, const unsigned* __restrict__ mwords, int NW, int s,
                                             ctab_t tab, f3 Pb, f3 Pt, f3 Pr, float half_n, float off,
-                                            int ox, int oy, unsigned rcx, unsigned rcy,
+                                            float ulo, float uhi, float vlo, float vhi,
                                             float& ar, float& ag, float& ab, unsigned& cnt) {
     for (int w = s; w < NW; w += REG_S) {
         unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)mwords[w]);
@@ -73,41 +75,50 @@ __device__ __forceinline__ void region_pass(const float4* __restrict__ region, c
             const float sc = fmaf(e.x, Pb.x, fmaf(e.y, Pt.x, e.z * Pr.x));
             const float tc = fmaf(e.x, Pb.y, fmaf(e.y, Pt.y, e.z * Pr.y));
             const float ma = fmaf(e.x, Pb.z, fmaf(e.y, Pt.z, e.z * Pr.z));
-            bool in;
-            if (CLS == 0) in = (ma > fabsf(sc)) && (ma > fabsf(tc));
-            else if (CLS == 1) in = (ma >= fabsf(sc)) && (ma > fabsf(tc));
-            else in = (ma >= fabsf(sc)) && (ma >= fabsf(tc));
+            // in-face test with the hardware's tie rule; each comparison's lane mask is taken by its own ballot (the compiler folds
+            // a ballot of ONE comparison into the v_cmp's SGPR result, not a ballot of their conjunction)
+            bool c1, c2;
+            if (CLS == 0) { c1 = ma > fabsf(sc); c2 = ma > fabsf(tc); }
+            else if (CLS == 1) { c1 = ma >= fabsf(sc); c2 = ma > fabsf(tc); }
+            else { c1 = ma >= fabsf(sc); c2 = ma >= fabsf(tc); }
+            unsigned long long inm = __builtin_amdgcn_ballot_w64(c1) & __builtin_amdgcn_ballot_w64(c2);
             // Lanes whose direction is not on this face (or, SUB, not in this region's cells) sit the sample out under the exec
-            // mask: no selects, and a wave none of whose lanes is in skips the rest (s_cbranch_execz).
+            // mask; a wave none of whose lanes is on the face skips the rest.  The (lane, sample) pairs taken are counted per wave
+            // with scalar instructions.
+            if (inm == 0) continue;
+            bool in = c1 && c2;
+            const float h = __builtin_amdgcn_rcpf(ma) * half_n;
+            const float u = fmaf(sc, h, off), v = fmaf(tc, h, off);                   // bordered tap coordinates, [0.5, n + 0.5]
+            const int il = (int)u, jl = (int)v;
+            if (SUB) {
+                // floor(u) in [ox, ox + rcx) <=> u in [ox, ox + rcx) (integer bounds): four float comparisons, no integer arithmetic
+                const bool c3 = u >= ulo, c4 = u < uhi, c5 = v >= vlo, c6 = v < vhi;
+                inm &= __builtin_amdgcn_ballot_w64(c3) & __builtin_amdgcn_ballot_w64(c4) & __builtin_amdgcn_ballot_w64(c5) & __builtin_amdgcn_ballot_w64(c6);
+                in = in && c3 && c4 && c5 && c6;
+            }
+            cnt += (unsigned)__builtin_popcountll(inm);
             if (in) {
-                const float h = __builtin_amdgcn_rcpf(ma) * half_n;
-                const float u = fmaf(sc, h, off), v = fmaf(tc, h, off);               // bordered tap coordinates, [0.5, n + 0.5]
-                int il = (int)u, jl = (int)v;
-                bool in2 = true;
-                if (SUB) {
-                    il -= ox; jl -= oy;
-                    in2 = ((unsigned)il < rcx) && ((unsigned)jl < rcy);
-                }
-                if (in2) {
-                    const float a = __builtin_amdgcn_fractf(u), b = __builtin_amdgcn_fractf(v);
-                    cnt += 1u;
-                    // whole 16-byte texels: ds_read_b128 runs at 256 B/clk/CU, the 12-byte form the compiler would pick at 96 (the
-                    // empty asm keeps the fourth component alive)
-                    const v4f* tp = (const v4f*)(region + (__mul24(jl, RS) + il));
-                    v4f q00 = tp[0], q10 = tp[1], q01 = tp[RS], q11 = tp[RS + 1];
-                    asm("" : "+v"(q00)); asm("" : "+v"(q10)); asm("" : "+v"(q01)); asm("" : "+v"(q11));
-                    // weights of the four taps with the sample weight folded in
-                    const float wgt = e.w;
-                    const float wa = wgt * a;
-                    const float w11 = wa * b;
-                    const float w10 = wa - w11;
-                    const float wb = wgt * b;
-                    const float w01 = wb - w11;
-                    const float w00 = (wgt - wa) - w01;
-                    ar = fmaf(w11, q11.x, fmaf(w01, q01.x, fmaf(w10, q10.x, fmaf(w00, q00.x, ar))));
-                    ag = fmaf(w11, q11.y, fmaf(w01, q01.y, fmaf(w10, q10.y, fmaf(w00, q00.y, ag))));
-                    ab = fmaf(w11, q11.z, fmaf(w01, q01.z, fmaf(w10, q10.z, fmaf(w00, q00.z, ab))));
-                }
+                const float a = __builtin_amdgcn_fractf(u), b = __builtin_amdgcn_fractf(v);
+                // whole 16-byte texels: ds_read_b128 runs at 256 B/clk/CU, the 12-byte form the compiler would pick at 96 (the
+                // empty asm keeps the fourth component alive); LDS byte address = jl * row + (il << 4) + base (the region's origin
+                // is folded into the base) in one shift-add and one 24-bit multiply-add
+                unsigned t16, addr;
+                asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(t16) : "v"(il), "s"(lds_base));
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(jl), "s"(RS * 16), "v"(t16));
+                lds_v4f_p tp = (lds_v4f_p)(unsigned long long)addr;
+                v4f q00 = tp[0], q10 = tp[1], q01 = tp[RS], q11 = tp[RS + 1];
+                asm("" : "+v"(q00)); asm("" : "+v"(q10)); asm("" : "+v"(q01)); asm("" : "+v"(q11));
+                // weights of the four taps with the sample weight folded in
+                const float wgt = e.w;
+                const float wa = wgt * a;
+                const float w11 = wa * b;
+                const float w10 = wa - w11;
+                const float wt = wgt - wa;
+                const float w01 = wt * b;
+                const float w00 = wt - w01;
+                ar = fmaf(w11, q11.x, fmaf(w01, q01.x, fmaf(w10, q10.x, fmaf(w00, q00.x, ar))));
+                ag = fmaf(w11, q11.y, fmaf(w01, q01.y, fmaf(w10, q10.y, fmaf(w00, q00.y, ag))));
+                ab = fmaf(w11, q11.z, fmaf(w01, q01.z, fmaf(w10, q10.z, fmaf(w00, q00.z, ab))));
             }
         }
     }
@@ -117,6 +128,7 @@ template <int RS, bool SUB>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mc_region(const RegArgs q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
     float4* region = (float4*)smem_r;
+    const unsigned lds_base = (unsigned)(unsigned long long)smem_r;      // LDS byte offset of the staged region (low half of the flat address)
     unsigned* masks = (unsigned*)(smem_r + RS * RS * 16);
     unsigned* any = masks + q.NR * q.NW;
     unsigned* dmax = any + q.NR;
@@ -218,16 +230,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         face_coords(f, T.x, T.y, T.z, Pt.x, Pt.y, Pt.z);
         face_coords(f, R.x, R.y, R.z, Pr.x, Pr.y, Pr.z);
         const unsigned* mw = masks + r * NW;
+        const unsigned pass_base = lds_base - (unsigned)(oy * RS + ox) * 16u;      // taps are addressed with face coordinates
         switch (f >> 1) {
-        case 0: region_pass<RS, SUB, 0>(region, mw, NW, s, tab, Pb, Pt, Pr, half_n, off, ox, oy, (unsigned)rcx, (unsigned)rcy, ar, ag, ab, cnt); break;
-        case 1: region_pass<RS, SUB, 1>(region, mw, NW, s, tab, Pb, Pt, Pr, half_n, off, ox, oy, (unsigned)rcx, (unsigned)rcy, ar, ag, ab, cnt); break;
-        default: region_pass<RS, SUB, 2>(region, mw, NW, s, tab, Pb, Pt, Pr, half_n, off, ox, oy, (unsigned)rcx, (unsigned)rcy, ar, ag, ab, cnt); break;
+        case 0: region_pass<RS, SUB, 0>(pass_base, mw, NW, s, tab, Pb, Pt, Pr, half_n, off, (float)ox, (float)(ox + rcx), (float)oy, (float)(oy + rcy), ar, ag, ab, cnt); break;
+        case 1: region_pass<RS, SUB, 1>(pass_base, mw, NW, s, tab, Pb, Pt, Pr, half_n, off, (float)ox, (float)(ox + rcx), (float)oy, (float)(oy + rcy), ar, ag, ab, cnt); break;
+        default: region_pass<RS, SUB, 2>(pass_base, mw, NW, s, tab, Pb, Pt, Pr, half_n, off, (float)ox, (float)(ox + rcx), (float)oy, (float)(oy + rcy), ar, ag, ab, cnt); break;
         }
     }
 
     // ---- 3. completeness check; a wave that missed a sample recomputes its slice with direct loads ----
-    const unsigned expect = (unsigned)(s == 0 ? q.expect[0] : (s == 1 ? q.expect[1] : (s == 2 ? q.expect[2] : q.expect[3])));
-    const bool healed = __builtin_amdgcn_ballot_w64(cnt != expect) != 0;
+    // cnt is a wave total (scalar): no (texel, sample) pair can be taken twice -- the in-region tests partition the tap positions
+    // exactly -- so the total is right exactly when no lane missed a sample
+    const unsigned expect = 64u * (unsigned)(s == 0 ? q.expect[0] : (s == 1 ? q.expect[1] : (s == 2 ? q.expect[2] : q.expect[3])));
+    const bool healed = cnt != expect;
     if (healed) {
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)p.src_bytes, 0x00020000);
         ar = 0.0f; ag = 0.0f; ab = 0.0f;
