@@ -58,68 +58,85 @@ __device__ __forceinline__ void face_coords(int f, float x, float y, float z, fl
     }
 }
 
-// One pass over the flagged samples of this wave's slice for the staged region.
+// One sample of a pass: accumulate it in the lanes whose direction falls into the staged region.
 // CLS = major axis of the region's face (0: x, 1: y, 2: z): the hardware's tie rule (z >= y >= x) in two comparisons.
+template <int RS, bool SUB, int CLS>
+__device__ __forceinline__ void region_sample(const v4f e, unsigned lds_base, f3 Pb, f3 Pt, f3 Pr, float half_n, float off,
+                                              float ulo, float uhi, float vlo, float vhi,
+                                              float& ar, float& ag, float& ab, unsigned& cnt) {
+    // (sc, tc, ma) = permuted frame * local direction, same FMA order as the direct kernel's L
+    const float sc = fmaf(e.x, Pb.x, fmaf(e.y, Pt.x, e.z * Pr.x));
+    const float tc = fmaf(e.x, Pb.y, fmaf(e.y, Pt.y, e.z * Pr.y));
+    const float ma = fmaf(e.x, Pb.z, fmaf(e.y, Pt.z, e.z * Pr.z));
+    // in-face test with the hardware's tie rule; each comparison's lane mask is taken by its own ballot (the compiler folds
+    // a ballot of ONE comparison into the v_cmp's SGPR result, not a ballot of their conjunction)
+    bool c1, c2;
+    if (CLS == 0) { c1 = ma > fabsf(sc); c2 = ma > fabsf(tc); }
+    else if (CLS == 1) { c1 = ma >= fabsf(sc); c2 = ma > fabsf(tc); }
+    else { c1 = ma >= fabsf(sc); c2 = ma >= fabsf(tc); }
+    unsigned long long inm = __builtin_amdgcn_ballot_w64(c1) & __builtin_amdgcn_ballot_w64(c2);
+    // Lanes whose direction is not on this face (or, SUB, not in this region's cells) sit the sample out under the exec
+    // mask; a wave none of whose lanes is on the face skips the rest.  The (lane, sample) pairs taken are counted per wave
+    // with scalar instructions.
+    if (inm == 0) return;
+    bool in = c1 && c2;
+    const float h = __builtin_amdgcn_rcpf(ma) * half_n;
+    const float u = fmaf(sc, h, off), v = fmaf(tc, h, off);                   // bordered tap coordinates, [0.5, n + 0.5]
+    const int il = (int)u, jl = (int)v;
+    if (SUB) {
+        // floor(u) in [ox, ox + rcx) <=> u in [ox, ox + rcx) (integer bounds): four float comparisons, no integer arithmetic
+        const bool c3 = u >= ulo, c4 = u < uhi, c5 = v >= vlo, c6 = v < vhi;
+        inm &= __builtin_amdgcn_ballot_w64(c3) & __builtin_amdgcn_ballot_w64(c4) & __builtin_amdgcn_ballot_w64(c5) & __builtin_amdgcn_ballot_w64(c6);
+        in = in && c3 && c4 && c5 && c6;
+    }
+    cnt += (unsigned)__builtin_popcountll(inm);
+    if (in) {
+        const float a = __builtin_amdgcn_fractf(u), b = __builtin_amdgcn_fractf(v);
+        // whole 16-byte texels: ds_read_b128 runs at 256 B/clk/CU, the 12-byte form the compiler would pick at 96 (the
+        // empty asm keeps the fourth component alive); LDS byte address = jl * row + (il << 4) + base (the region's origin
+        // is folded into the base) in one shift-add and one 24-bit multiply-add
+        unsigned t16, addr;
+        asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(t16) : "v"(il), "s"(lds_base));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(jl), "s"(RS * 16), "v"(t16));
+        lds_v4f_p tp = (lds_v4f_p)(unsigned long long)addr;
+        v4f q00 = tp[0], q10 = tp[1], q01 = tp[RS], q11 = tp[RS + 1];
+        asm("" : "+v"(q00)); asm("" : "+v"(q10)); asm("" : "+v"(q01)); asm("" : "+v"(q11));
+        // weights of the four taps with the sample weight folded in
+        const float wgt = e.w;
+        const float wa = wgt * a;
+        const float w11 = wa * b;
+        const float w10 = wa - w11;
+        const float wt = wgt - wa;
+        const float w01 = wt * b;
+        const float w00 = wt - w01;
+        ar = fmaf(w11, q11.x, fmaf(w01, q01.x, fmaf(w10, q10.x, fmaf(w00, q00.x, ar))));
+        ag = fmaf(w11, q11.y, fmaf(w01, q01.y, fmaf(w10, q10.y, fmaf(w00, q00.y, ag))));
+        ab = fmaf(w11, q11.z, fmaf(w01, q01.z, fmaf(w10, q10.z, fmaf(w00, q00.z, ab))));
+    }
+}
+
+// One pass over the flagged samples of this wave's slice for the staged region.  Samples are taken two at a time so that the
+// second table entry's scalar load is in flight while the first sample computes.
 template <int RS, bool SUB, int CLS>
 __device__ __forceinline__ void region_pass(unsigned lds_base, const unsigned* __restrict__ mwords, int NW, int s,
                                             ctab_t tab, f3 Pb, f3 Pt, f3 Pr, float half_n, float off,
                                             float ulo, float uhi, float vlo, float vhi,
                                             float& ar, float& ag, float& ab, unsigned& cnt) {
+    unsigned mnext = s < NW ? (unsigned)__builtin_amdgcn_readfirstlane((int)mwords[s]) : 0u;
     for (int w = s; w < NW; w += REG_S) {
-        unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)mwords[w]);
+        unsigned m = mnext;
+        mnext = w + REG_S < NW ? (unsigned)__builtin_amdgcn_readfirstlane((int)mwords[w + REG_S]) : 0u;
+        ctab_t tw = tab + (w << 5);
         while (m) {
-            const int i = (w << 5) + __builtin_ctz(m);
+            const int i0 = __builtin_ctz(m);
             m &= m - 1u;
-            const v4f e = tab[i];
-            // (sc, tc, ma) = permuted frame * local direction, same FMA order as the direct kernel's L
-            const float sc = fmaf(e.x, Pb.x, fmaf(e.y, Pt.x, e.z * Pr.x));
-            const float tc = fmaf(e.x, Pb.y, fmaf(e.y, Pt.y, e.z * Pr.y));
-            const float ma = fmaf(e.x, Pb.z, fmaf(e.y, Pt.z, e.z * Pr.z));
-            // in-face test with the hardware's tie rule; each comparison's lane mask is taken by its own ballot (the compiler folds
-            // a ballot of ONE comparison into the v_cmp's SGPR result, not a ballot of their conjunction)
-            bool c1, c2;
-            if (CLS == 0) { c1 = ma > fabsf(sc); c2 = ma > fabsf(tc); }
-            else if (CLS == 1) { c1 = ma >= fabsf(sc); c2 = ma > fabsf(tc); }
-            else { c1 = ma >= fabsf(sc); c2 = ma >= fabsf(tc); }
-            unsigned long long inm = __builtin_amdgcn_ballot_w64(c1) & __builtin_amdgcn_ballot_w64(c2);
-            // Lanes whose direction is not on this face (or, SUB, not in this region's cells) sit the sample out under the exec
-            // mask; a wave none of whose lanes is on the face skips the rest.  The (lane, sample) pairs taken are counted per wave
-            // with scalar instructions.
-            if (inm == 0) continue;
-            bool in = c1 && c2;
-            const float h = __builtin_amdgcn_rcpf(ma) * half_n;
-            const float u = fmaf(sc, h, off), v = fmaf(tc, h, off);                   // bordered tap coordinates, [0.5, n + 0.5]
-            const int il = (int)u, jl = (int)v;
-            if (SUB) {
-                // floor(u) in [ox, ox + rcx) <=> u in [ox, ox + rcx) (integer bounds): four float comparisons, no integer arithmetic
-                const bool c3 = u >= ulo, c4 = u < uhi, c5 = v >= vlo, c6 = v < vhi;
-                inm &= __builtin_amdgcn_ballot_w64(c3) & __builtin_amdgcn_ballot_w64(c4) & __builtin_amdgcn_ballot_w64(c5) & __builtin_amdgcn_ballot_w64(c6);
-                in = in && c3 && c4 && c5 && c6;
-            }
-            cnt += (unsigned)__builtin_popcountll(inm);
-            if (in) {
-                const float a = __builtin_amdgcn_fractf(u), b = __builtin_amdgcn_fractf(v);
-                // whole 16-byte texels: ds_read_b128 runs at 256 B/clk/CU, the 12-byte form the compiler would pick at 96 (the
-                // empty asm keeps the fourth component alive); LDS byte address = jl * row + (il << 4) + base (the region's origin
-                // is folded into the base) in one shift-add and one 24-bit multiply-add
-                unsigned t16, addr;
-                asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(t16) : "v"(il), "s"(lds_base));
-                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(jl), "s"(RS * 16), "v"(t16));
-                lds_v4f_p tp = (lds_v4f_p)(unsigned long long)addr;
-                v4f q00 = tp[0], q10 = tp[1], q01 = tp[RS], q11 = tp[RS + 1];
-                asm("" : "+v"(q00)); asm("" : "+v"(q10)); asm("" : "+v"(q01)); asm("" : "+v"(q11));
-                // weights of the four taps with the sample weight folded in
-                const float wgt = e.w;
-                const float wa = wgt * a;
-                const float w11 = wa * b;
-                const float w10 = wa - w11;
-                const float wt = wgt - wa;
-                const float w01 = wt * b;
-                const float w00 = wt - w01;
-                ar = fmaf(w11, q11.x, fmaf(w01, q01.x, fmaf(w10, q10.x, fmaf(w00, q00.x, ar))));
-                ag = fmaf(w11, q11.y, fmaf(w01, q01.y, fmaf(w10, q10.y, fmaf(w00, q00.y, ag))));
-                ab = fmaf(w11, q11.z, fmaf(w01, q01.z, fmaf(w10, q10.z, fmaf(w00, q00.z, ab))));
-            }
+            const bool two = m != 0u;
+            const int i1 = two ? __builtin_ctz(m) : i0;
+            m &= m - 1u;                                                   // no-op when m is already 0
+            const v4f e0 = tw[i0];
+            const v4f e1 = tw[i1];
+            region_sample<RS, SUB, CLS>(e0, lds_base, Pb, Pt, Pr, half_n, off, ulo, uhi, vlo, vhi, ar, ag, ab, cnt);
+            if (two) region_sample<RS, SUB, CLS>(e1, lds_base, Pb, Pt, Pr, half_n, off, ulo, uhi, vlo, vhi, ar, ag, ab, cnt);
         }
     }
 }
@@ -170,8 +187,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         atomicMax(dmax, __float_as_uint(sqrtf(d2)));                 // non-negative floats order like their bit patterns
     }
     __syncthreads();
-    // |L_texel - L_centre| <= |M_texel - M_centre|_F for a unit local direction; inflated for the rounding of both evaluations
-    const float delta = __uint_as_float(*dmax) * 1.0001f + 2e-6f;
+    // |L_texel - L_centre| <= |M_texel - M_centre|_2 for a unit local direction.  Both frames are orthonormal, so M_t - M_c =
+    // (Rot - I) M_c with singular values {0, 2 sin(theta/2), 2 sin(theta/2)}: the spectral norm is the Frobenius norm / sqrt(2).
+    // Inflated for the frames' own rounding (1e-7) and that of both evaluations.
+    const float delta = __uint_as_float(*dmax) * 0.70710678f * 1.001f + 4e-6f;
     for (int i = tid; i < p.n_tab; i += 1024) {
         const v4f e = tab[i];
         const float Lx = fmaf(e.x, Bc.x, fmaf(e.y, Tc.x, e.z * Rc.x));
