@@ -50,12 +50,6 @@ def test_c4_constant_environment(gpu):
     gpu.GPU_DestroyTexture(irr); gpu.GPU_DestroyTexture(spec); gpu.GPU_DestroyTexture(tex)
 
 
-@pytest.fixture(scope="module")
-def c2_env():
-    from pbrhip import synth
-    return synth.synth_env(1024, seed=0x5EED0001, workers=6)
-
-
 def test_c2_linearity_and_oracle_rows(gpu, c2_env):
     """C2 size (512^2, 10 mips, 1024^2 env): the filter is linear in the environment; a few rows of every mip match the oracle."""
     import pbrhip, pbr_oracle as O

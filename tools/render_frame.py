@@ -32,8 +32,8 @@ def write_png(path, rgb):
 def main():
     out = sys.argv[1]
     W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1280, 720)
+    env = synth.synth_env(512, seed=0x5EED0001, workers=6)       # forked workers: before the HIP runtime is initialised
     L = pbrhip.init()
-    env = synth.synth_env(512, seed=0x5EED0001, workers=6)
     env_tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, 512, 512, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
     maps = pbrhip.PBR_IBLMaps()
     L.PBR_MakeIBLMaps(C.byref(maps), 32, 256, 256)
