@@ -161,6 +161,28 @@ def main():
             dist.init_process_group("gloo")
     L = pbrhip.init(device=dev_index)
     L.GPUX_EnableOpTiming(1)
+    # The exchange step runs in the C host layer (host/pbr_gather.c: PBR_GatherUnits / PBR_GatherBands on grouped ncclSend /
+    # ncclRecv); this script only bootstraps the communicator (the library never owns one).  PBR_BENCH_GATHER=torch selects
+    # the same exchange through torch.distributed P2P ops instead; the gloo rehearsal always does.
+    comm, gather_impl = None, "none"
+    if world > 1:
+        gather_impl = "torch.distributed"
+        if backend == "nccl" and os.environ.get("PBR_BENCH_GATHER", "c") != "torch":
+            ok = 1
+            try:
+                uid = [pbrhip.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                comm = pbrhip.rccl_comm_init(world, rank, uid[0])
+            except Exception as e:                                  # pragma: no cover (reported in the JSON line, never silent)
+                ok = 0
+                print(f"bench.py: rank {rank}: RCCL communicator for the C gather failed ({e!r}); using torch.distributed P2P", file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                gather_impl = "PBR_GatherUnits (C host layer, RCCL)"
+            else:
+                comm = None
+                gather_impl = "torch.distributed (C gather unavailable)"
 
     # ---- resources: env cube (level 0 resident), output maps over torch-owned HBM (so RCCL can move them)
     env_tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, W, W, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
@@ -203,7 +225,9 @@ def main():
     # the exchange is the same every step: the send/recv descriptors (views of the output memory) are built once
     gather_ops, staged = [], []
     if world > 1:
-        if rank == 0:
+        if comm is not None:
+            pass                                                    # PBR_GatherUnits derives the ranges itself
+        elif rank == 0:
             for r in range(1, world):
                 for u in all_units[r]:
                     dst = unit_slice(*u)
@@ -221,9 +245,17 @@ def main():
         L.GPU_OpGenerateMipmaps(graph, env_tex)                                   # K2 (+ apron rebuild on first sample)
         L.PBR_RecordUnits(pipes, graph, arena, env_tex, C.byref(maps), my_units, n_my)
         L.GPU_GraphSubmit(graph)
-        L.GPU_GraphWait(graph)
+        if comm is not None:                                                      # the exchange follows the kernels on the graph's own stream
+            moved = L.PBR_GatherUnits(comm, L.GPUX_GraphStream(graph), 0, world, rank, C.byref(maps), 1, W)
+            if moved < 0:
+                raise RuntimeError(f"PBR_GatherUnits failed ({moved})")
+        L.GPU_GraphWait(graph)                                                    # ... and this waits for both
         L.GPU_ResetDescriptorArena(arena)
         t_b = time.perf_counter()
+        if comm is not None:                                                      # split by the kernels' own event timings
+            k_s = sum(L.GPUX_GraphTimedOpMs(graph, i) for i in range(L.GPUX_GraphTimedOpCount(graph))) * 1e-3
+            phase["compute"] += min(k_s, t_b - t_a); phase["exchange"] += max(0.0, t_b - t_a - k_s)
+            return
         phase["compute"] += t_b - t_a
         if world > 1:                                                             # one grouped RCCL exchange: tiles -> rank 0
             if backend == "nccl":
@@ -270,7 +302,8 @@ def main():
         dist.all_gather(gathered, pt)
         step_split = {"compute_ms_per_step_by_rank": [float(g[0]) / args.steps * 1e3 for g in gathered],
                       "exchange_ms_per_step_by_rank": [float(g[1]) / args.steps * 1e3 for g in gathered],
-                      "bytes_sent_by_rank": [0] + [int(sum(unit_slice(*u).numel() * 4 for u in all_units[r])) for r in range(1, world)]}
+                      "bytes_sent_by_rank": [0] + [int(sum(unit_slice(*u).numel() * 4 for u in all_units[r])) for r in range(1, world)],
+                      "gather": gather_impl}
 
     total_texels = sum(6 * max(1, spec_size >> m) ** 2 for m in range(n_mips)) + 6 * irr_size * irr_size
     ms_per_step = elapsed / args.steps * 1e3
@@ -372,7 +405,7 @@ def main():
             extra["lightgrid_sweep_error"] = repr(e)
 
     if not args.no_shade and not args.no_c5:                      # every rank takes part (screen bands + gather)
-        c5 = shade_c5_bench(L, pbrhip, env_tex, rank, world, backend, torch, dist, c5_gbd, frames=args.c5_frames)
+        c5 = shade_c5_bench(L, pbrhip, env_tex, rank, world, backend, torch, dist, c5_gbd, frames=args.c5_frames, comm=comm)
         if rank == 0:
             extra["shade_c5"] = c5
 
@@ -474,7 +507,7 @@ def shade_bench(L, pbrhip, maps, world, frames=20):
     return res
 
 
-def shade_c5_bench(L, pbrhip, env_tex, rank, world, backend, torch, dist, gbd, frames=10):
+def shade_c5_bench(L, pbrhip, env_tex, rank, world, backend, torch, dist, gbd, frames=10, comm=None):
     """C5: 7680x4320 synthetic 'temple' G-buffer, deferred shade split into horizontal screen bands over the ranks, bands
     gathered to rank 0 every frame (one grouped exchange).  IBL maps at the reference's sizes are computed redundantly on
     every rank (9 MB: cheaper than communicating).  Collective-safe: ranks agree on success before the timed loop."""
@@ -513,8 +546,12 @@ def shade_c5_bench(L, pbrhip, env_tex, rank, world, backend, torch, dist, gbd, f
 
     def frame(gather=True):
         L.PBR_RecordLightingPass(lp, g, C.byref(glob), r0, r1)
-        L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
-        if world > 1 and gather:
+        L.GPU_GraphSubmit(g)
+        if world > 1 and gather and comm is not None:                             # C host layer: bands -> rank 0 behind the kernel, same stream
+            if L.PBR_GatherBands(comm, L.GPUX_GraphStream(g), 0, world, rank, gb.lighting_result) < 0:
+                raise RuntimeError("PBR_GatherBands failed")
+        L.GPU_GraphWait(g)
+        if world > 1 and gather and comm is None:
             ops, staged = [], []
             if rank == 0:
                 for r in range(1, world):

@@ -58,6 +58,9 @@ GPU_API void* GPUX_GraphStream(GPU_Graph* graph);                               
  * [mip][layer][y][x] tight; the caller keeps the allocation alive and frees it after GPU_DestroyTexture. ---- */
 GPU_API GPU_Texture* GPUX_MakeTextureExternal(GPU_Format format, uint32_t width, uint32_t height, uint32_t depth, GPU_TextureFlags flags,
                                               void* device_memory, uint64_t device_bytes);
+/* Tell the backend that the texture's memory was written behind its back (RCCL receive, torch, any other library working on
+ * GPUX_TextureDevicePtr / external memory): the lazily built sampler twins (apron, cells) are rebuilt before the next use. */
+GPU_API void GPUX_InvalidateTexture(GPU_Texture* texture);
 GPU_API uint64_t GPUX_TextureTotalBytes(const GPU_Texture* texture);
 GPU_API uint64_t GPUX_TextureMipOffset(const GPU_Texture* texture, uint32_t mip_level);
 

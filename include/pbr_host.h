@@ -74,6 +74,27 @@ void PBR_RecordUnits(PBR_IBLPipelines* p, GPU_Graph* graph, GPU_DescriptorArena*
 uint32_t PBR_PartitionIBL(uint32_t specular_size, uint32_t min_size, uint32_t irradiance_size, uint32_t env_size,
                           int world, int rank, PBR_WorkUnit* out, uint32_t capacity);
 
+/* ---- the exchange step of the multi-GPU job: RCCL over xGMI, one grouped batch of point-to-point transfers.
+ * The reference has no counterpart (single queue, gpu_vulkan.c:1040-1106).  `nccl_comm` is the caller's ncclComm_t (opaque:
+ * the library does not own the bootstrap), `stream` the hipStream_t the transfers are enqueued on -- pass
+ * GPUX_GraphStream(graph) after GPU_GraphSubmit(graph) and the exchange follows the graph's kernels without a host round
+ * trip; GPU_GraphWait(graph) then also waits for the exchange.  Negative return values are PBR_E_*. ---- */
+enum { PBR_OK = 0, PBR_E_BADARG = -1, PBR_E_COMM = -2 };
+typedef struct PBR_XferRange { void* ptr; uint64_t bytes; int peer; } PBR_XferRange;    /* device pointer, byte count, peer rank */
+/* ncclGroupStart; ncclRecv x n_recvs; ncclSend x n_sends; ncclGroupEnd (a rank may send to itself) */
+int PBR_ExchangeRanges(void* nccl_comm, void* stream, const PBR_XferRange* sends, uint32_t n_sends,
+                       const PBR_XferRange* recvs, uint32_t n_recvs);
+/* The bytes of one work unit inside its texture: contiguous in the [mip][face][y][x] layout (rows of one face, or whole faces). */
+int PBR_UnitByteRange(const PBR_IBLMaps* maps, const PBR_WorkUnit* unit, GPU_Texture** texture, uint64_t* offset, uint64_t* bytes);
+/* After every rank has run its share (PBR_PartitionIBL(..., world, rank) + PBR_RecordUnits): ranks != root send their units,
+ * root receives all of them in place, so that `maps` on root holds the whole result.  Every rank must pass the same
+ * min_size / env_size it partitioned with.  Returns the bytes this rank sent or received (0 when world == 1). */
+int64_t PBR_GatherUnits(void* nccl_comm, void* stream, int root, int world, int rank, const PBR_IBLMaps* maps,
+                        uint32_t min_size, uint32_t env_size);
+/* Screen-band split of the shade pass (C5): rank r owns rows [height*r/world, height*(r+1)/world) of the frame */
+void PBR_BandRows(uint32_t height, int world, int rank, uint32_t* row0, uint32_t* row1);
+int64_t PBR_GatherBands(void* nccl_comm, void* stream, int root, int world, int rank, GPU_Texture* frame);
+
 /* ---- camera + Globals: utils/camera.h:95-120 and render.cpp:962-991 ---- */
 typedef struct PBR_Globals {            /* RendererGlobalsBuffer, render.h:122-136; column-major mat4 */
     float clip_space_from_world[16];

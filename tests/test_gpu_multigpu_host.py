@@ -1,0 +1,151 @@
+"""The multi-GPU host layer on a one-GPU lease: the C gather (host/pbr_gather.c) on a 1-rank RCCL communicator, submission
+order between graphs in flight, and invalidation of sampler twins after writes the backend cannot see."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _maps_32(L, pbrhip):
+    from pbrhip import synth
+    env = synth.synth_env(32, seed=0x5EED00AA)
+    tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, 32, 32, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+    maps = pbrhip.PBR_IBLMaps()
+    L.PBR_MakeIBLMaps(C.byref(maps), 8, 64, 32)
+    L.PBR_GenPrefilteredEnvMap(tex, maps.tex_specular_env_map, 1)
+    L.PBR_GenIrradianceMap(tex, maps.irradiance_map)
+    return tex, maps
+
+
+def test_rccl_gather_on_single_rank_communicator(gpu):
+    """PBR_ExchangeRanges (ncclGroupStart / ncclRecv / ncclSend / ncclGroupEnd) on a 1-rank communicator: every unit a rank of a
+    2- and 3-way split would send travels to self into a second buffer and arrives bit-identical; PBR_UnitByteRange addresses
+    exactly the unit's texels; the world == 1 gather is a no-op."""
+    import pbrhip
+    L = gpu
+    tex, maps = _maps_32(L, pbrhip)
+    comm = pbrhip.rccl_comm_init(1, 0, pbrhip.rccl_unique_id())
+    try:
+        g = L.GPU_MakeGraph()
+        stream = L.GPUX_GraphStream(g)
+        assert L.PBR_GatherUnits(comm, stream, 0, 1, 0, C.byref(maps), 1, 32) == 0
+        for (t, name) in ((maps.tex_specular_env_map, "spec"), (maps.irradiance_map, "irr")):
+            nbytes = L.GPUX_TextureTotalBytes(t)
+            dst = L.GPU_MakeBuffer(nbytes, pbrhip.BufferFlag_GPU, None)
+            host = L.GPU_MakeBuffer(nbytes, pbrhip.BufferFlag_CPU, None)
+            zero = np.zeros(nbytes, np.uint8)
+            zbuf = L.GPU_MakeBuffer(nbytes, pbrhip.BufferFlag_CPU, zero.ctypes.data_as(C.c_void_p))
+            L.GPU_OpCopyBufferToBuffer(g, zbuf, dst, 0, 0, nbytes); L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+            src_ptr = L.GPUX_TextureDevicePtr(t, 0)
+            dst_ptr = L.GPUX_BufferDevicePtr(dst)
+            sends, recvs, covered = [], [], np.zeros(nbytes, bool)
+            for world in (2, 3):
+                for rank in range(1, world):
+                    units, n = pbrhip.partition(32, 1, 8, 32, world, rank)
+                    for i in range(n):
+                        u = units[i]
+                        if (u.kind == pbrhip.Unit_Irradiance) != (name == "irr"):
+                            continue
+                        tp = pbrhip.TexP(); off = C.c_uint64(); nb = C.c_uint64()
+                        assert L.PBR_UnitByteRange(C.byref(maps), C.byref(u), C.byref(tp), C.byref(off), C.byref(nb)) == 0
+                        # the same range from the layout definition ([mip][face][y][x], 16 B texels)
+                        size = 8 if name == "irr" else max(1, 32 >> u.mip)
+                        base = 0 if name == "irr" else L.pbrk_level_offset(32, u.mip) * 16
+                        a = base + ((u.face0 * size + u.row0) * size) * 16
+                        b = base + (((u.face1 - 1) * size + u.row1) * size) * 16
+                        assert (off.value, nb.value) == (a, b - a)
+                        if covered[a:b].any():
+                            continue                           # ranges of the 2-way and the 3-way split overlap: send each byte once
+                        covered[a:b] = True
+                        sends.append(pbrhip.PBR_XferRange(src_ptr + a, b - a, 0)); recvs.append(pbrhip.PBR_XferRange(dst_ptr + a, b - a, 0))
+            assert sends
+            S = (pbrhip.PBR_XferRange * len(sends))(*sends); R = (pbrhip.PBR_XferRange * len(recvs))(*recvs)
+            assert L.PBR_ExchangeRanges(comm, stream, S, len(sends), R, len(recvs)) == 0
+            L.GPU_OpCopyBufferToBuffer(g, dst, host, 0, 0, nbytes)           # same stream: follows the exchange
+            L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+            got = np.frombuffer((C.c_char * nbytes).from_address(host.contents.data), np.uint8)
+            want = np.concatenate([pbrhip.read_mip(t, m).view(np.uint8).ravel() for m in range(t.contents.mip_level_count)])
+            assert np.array_equal(got[covered], want[covered]) and not got[~covered].any() and covered.any()
+            for b_ in (dst, host, zbuf):
+                L.GPU_DestroyBuffer(b_)
+        # argument checking happens before anything is enqueued
+        bad = (pbrhip.PBR_XferRange * 1)(pbrhip.PBR_XferRange(None, 16, 0))
+        assert L.PBR_ExchangeRanges(comm, stream, bad, 1, None, 0) == -1
+        assert L.PBR_GatherUnits(None, stream, 0, 2, 1, C.byref(maps), 1, 32) == -1
+        L.GPU_DestroyGraph(g)
+    finally:
+        pbrhip.rccl_comm_destroy(comm)
+    L.PBR_DestroyIBLMaps(C.byref(maps)); L.GPU_DestroyTexture(tex)
+
+
+def test_two_graphs_in_flight_keep_submission_order(gpu):
+    """The reference keeps two graphs in flight on one queue (main.cpp:49-51, 91-99): graph B, submitted while graph A still
+    runs, must see what A wrote.  A = a 256^2 prefilter chain (milliseconds), B = read-back of its mips; no wait in between."""
+    import pbrhip
+    from pbrhip import synth
+    L = gpu
+    env = synth.synth_env(128, seed=0x5EED00AB)
+    tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, 128, 128, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+    maps = pbrhip.PBR_IBLMaps()
+    L.PBR_MakeIBLMaps(C.byref(maps), 8, 64, 256)
+    spec = maps.tex_specular_env_map
+    L.PBR_GenPrefilteredEnvMap(tex, spec, 16)                       # reference result, sequential
+    want = [pbrhip.read_mip(spec, m).copy() for m in range(5)]
+    gA, gB = L.GPU_MakeGraph(), L.GPU_MakeGraph()
+    for m in range(5):
+        L.GPU_OpClearColorF(gA, spec, m, 0.0, 0.0, 0.0, 0.0)
+    L.GPU_GraphSubmit(gA); L.GPU_GraphWait(gA)
+    pipes = L.PBR_MakeIBLPipelines(); arena = L.GPU_MakeDescriptorArena()
+    units, n = pbrhip.partition(256, 16, 0, 128, 1, 0)
+    bufs = [L.GPU_MakeBuffer(L.GPUX_TextureMipBytes(spec, m), pbrhip.BufferFlag_CPU, None) for m in range(5)]
+    L.PBR_RecordUnits(pipes, gA, arena, tex, C.byref(maps), units, n)
+    for m in range(5):
+        L.GPUX_OpCopyTextureMipToBuffer(gB, spec, m, bufs[m], 0)
+    L.GPU_GraphSubmit(gA)
+    L.GPU_GraphSubmit(gB)                                           # A is still running
+    L.GPU_GraphWait(gB); L.GPU_GraphWait(gA)
+    for m in range(5):
+        nb = L.GPUX_TextureMipBytes(spec, m)
+        got = np.frombuffer((C.c_char * nb).from_address(bufs[m].contents.data), np.float32).reshape(want[m].shape)
+        assert np.array_equal(got.view(np.uint32), want[m].view(np.uint32)), m
+    for b in bufs:
+        L.GPU_DestroyBuffer(b)
+    L.GPU_DestroyGraph(gA); L.GPU_DestroyGraph(gB); L.GPU_DestroyDescriptorArena(arena); L.PBR_DestroyIBLPipelines(pipes)
+    L.PBR_DestroyIBLMaps(C.byref(maps)); L.GPU_DestroyTexture(tex)
+
+
+def test_invalidate_texture_after_external_write(gpu):
+    """A texture over caller-owned memory (GPUX_MakeTextureExternal: where RCCL receives into) is sampled through lazily built
+    twins; after the memory changes behind the backend's back GPUX_InvalidateTexture makes the next use rebuild them."""
+    import pbrhip
+    from pbrhip import synth
+    L = gpu
+    envA = synth.synth_env(32, seed=0x5EED00AA)
+    envB = np.ascontiguousarray(envA[[1, 0, 3, 2, 5, 4]] * np.float32(0.5)); envB[..., 3] = 1.0
+    nbytes = envA.nbytes
+    store = L.GPU_MakeBuffer(nbytes, pbrhip.BufferFlag_GPU, None)
+    ext = L.GPUX_MakeTextureExternal(pbrhip.Format_RGBA32F, 32, 32, 1, pbrhip.TextureFlag_Cubemap, L.GPUX_BufferDevicePtr(store), nbytes)
+    out = pbrhip.make_texture(pbrhip.Format_RGBA32F, 8, 8, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_StorageImage)
+    ref = {}
+    g = L.GPU_MakeGraph()
+    for name, env in (("A", envA), ("B", envB)):                    # what the irradiance of each environment is
+        t = pbrhip.make_texture(pbrhip.Format_RGBA32F, 32, 32, pbrhip.TextureFlag_Cubemap, env)
+        L.PBR_GenIrradianceMap(t, out); ref[name] = pbrhip.read_mip(out, 0).copy(); L.GPU_DestroyTexture(t)
+    assert not np.array_equal(ref["A"], ref["B"])
+
+    def write(env):                                                 # writes the buffer, not the texture: invisible to the backend
+        up = L.GPU_MakeBuffer(nbytes, pbrhip.BufferFlag_CPU, np.ascontiguousarray(env).ctypes.data_as(C.c_void_p))
+        L.GPU_OpCopyBufferToBuffer(g, up, store, 0, 0, nbytes); L.GPU_GraphSubmit(g); L.GPU_GraphWait(g); L.GPU_DestroyBuffer(up)
+
+    write(envA); L.GPUX_InvalidateTexture(ext)
+    L.PBR_GenIrradianceMap(ext, out)
+    assert np.array_equal(pbrhip.read_mip(out, 0), ref["A"])
+    write(envB)
+    L.PBR_GenIrradianceMap(ext, out)                                # stale twin: still A's values (this is the hazard)
+    assert np.array_equal(pbrhip.read_mip(out, 0), ref["A"])
+    L.GPUX_InvalidateTexture(ext)
+    L.PBR_GenIrradianceMap(ext, out)
+    assert np.array_equal(pbrhip.read_mip(out, 0), ref["B"])
+    L.GPU_DestroyGraph(g); L.GPU_DestroyTexture(out); L.GPU_DestroyTexture(ext); L.GPU_DestroyBuffer(store)

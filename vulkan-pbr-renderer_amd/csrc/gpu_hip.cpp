@@ -112,6 +112,7 @@ struct GPU_Graph {
     hipStream_t cur = nullptr;                     // stream the op being executed launches on (stream, or a side stream)
     std::vector<hipStream_t> side;                 // side streams for overlapping independent tile dispatches (created on first use)
     std::vector<hipEvent_t> sync_ev;               // untimed fork/join events
+    hipEvent_t order_ev = nullptr;                 // recorded on this graph's stream when the NEXT submitted graph must follow it
     size_t sync_used = 0;
     std::vector<Op> ops;
     bool submitted = false;
@@ -139,6 +140,7 @@ struct TableKey {
 };
 
 static struct {
+    GPU_Graph* last_submitted = nullptr;            // submission order between graphs (the reference has one queue: gpu_vulkan.c:2481)
     int tile_streams = -1;                          // side streams for small independent precompute dispatches (-1: PBR_TILE_STREAMS or 4)
     bool init = false;
     int device = -1;
@@ -483,6 +485,12 @@ GPU_API void* GPUX_TextureDevicePtr(GPU_Texture* tex, uint32_t mip) {
     TextureImpl* t = (TextureImpl*)tex;
     return (char*)t->dev + t->mip_offset[mip];
 }
+GPU_API void GPUX_InvalidateTexture(GPU_Texture* tex) {
+    GPU_REQUIRE_V(tex, "GPUX_InvalidateTexture: NULL texture");
+    TextureImpl* t = (TextureImpl*)tex;
+    t->bordered_valid = false; t->lut_cells_valid = false;          // ensure_bordered() drops the cells twin with the apron
+    for (char& v : t->cells_valid) v = 0;
+}
 GPU_API void* GPUX_BufferDevicePtr(GPU_Buffer* buf) { return buf ? ((BufferImpl*)buf)->dev : nullptr; }
 
 // ------------------------------------------------------------------------------------------
@@ -708,6 +716,8 @@ GPU_API void GPU_DestroyGraph(GPU_Graph* g) {
     for (hipStream_t s : g->side) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : g->sync_ev) (void)hipEventDestroy(e);
+    if (g->order_ev) (void)hipEventDestroy(g->order_ev);
+    if (G.last_submitted == g) G.last_submitted = nullptr;        // idle by contract (gpu.h:453): nothing left to order against
     (void)hipStreamDestroy(g->stream);
     delete g;
 }
@@ -1500,6 +1510,17 @@ GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
     size_t ev_used = 0;
     g->sync_used = 0;
     g->cur = g->stream;
+    // Submission order is execution order, as on the reference's single queue (vkQueueSubmit, gpu_vulkan.c:2481-2530): a graph
+    // submitted while another one is still in flight (main.cpp:49-51, 91-99 keeps two) starts after everything enqueued so far on
+    // the previous graph's stream -- its kernels, lazily built sampler twins, and any exchange the caller appended through
+    // GPUX_GraphStream.  Side streams fork from g->stream, so they inherit the dependency.
+    if (G.last_submitted && G.last_submitted != g) {
+        GPU_Graph* prev = G.last_submitted;
+        if (!prev->order_ev) HIP_OK(hipEventCreateWithFlags(&prev->order_ev, hipEventDisableTiming));
+        HIP_OK(hipEventRecord(prev->order_ev, prev->stream));
+        HIP_OK(hipStreamWaitEvent(g->stream, prev->order_ev, 0));
+    }
+    G.last_submitted = g;
     // Row-ranged precompute dispatches (the work units of a partitioned job) are too small to keep 256 CUs x 8 waves busy one
     // at a time: consecutive ones whose outputs are disjoint and which do not read each other's output go round-robin onto
     // side streams, fenced by a fork event before the first and join events after the last.  Everything else stays in order.

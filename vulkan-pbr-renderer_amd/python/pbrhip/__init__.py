@@ -60,6 +60,10 @@ class PBR_WorkUnit(C.Structure):
                 ("row0", C.c_uint32), ("row1", C.c_uint32), ("cost", C.c_double)]
 
 
+class PBR_XferRange(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_uint64), ("peer", C.c_int)]
+
+
 class PBR_Globals(C.Structure):
     _fields_ = [(n, C.c_float * 16) for n in ("clip_space_from_world", "clip_space_from_view", "world_space_from_clip",
                                               "view_space_from_clip", "view_space_from_world", "world_space_from_view",
@@ -162,6 +166,7 @@ PROTOTYPES = {
     "GPUX_OpCopyTextureMipToBuffer": (None, [VP, TexP, U32, BufP, U32]), "GPUX_OpCopyBufferToTextureMip": (None, [VP, BufP, U32, TexP, U32]),
     "GPUX_TextureMipBytes": (C.c_uint64, [TexP, U32]), "GPUX_TextureDevicePtr": (VP, [TexP, U32]), "GPUX_BufferDevicePtr": (VP, [BufP]),
     "GPUX_MakeTextureExternal": (TexP, [C.c_int, U32, U32, U32, C.c_int, VP, C.c_uint64]),
+    "GPUX_InvalidateTexture": (None, [TexP]),
     "GPUX_TextureTotalBytes": (C.c_uint64, [TexP]), "GPUX_TextureMipOffset": (C.c_uint64, [TexP, U32]),
     "GPUX_MakeCubemapFromEquirect": (TexP, [VP, U32, U32, U32, C.c_int]),
     "GPUX_GraphStream": (VP, [VP]), "GPUX_EnableOpTiming": (None, [C.c_int]), "GPUX_SetTileStreams": (None, [C.c_int]), "GPUX_GraphTimedOpCount": (U32, [VP]),
@@ -178,6 +183,11 @@ PROTOTYPES = {
     "PBR_MakeIBLPipelines": (VP, []), "PBR_DestroyIBLPipelines": (None, [VP]),
     "PBR_RecordUnits": (None, [VP, VP, VP, TexP, C.POINTER(PBR_IBLMaps), C.POINTER(PBR_WorkUnit), U32]),
     "PBR_PartitionIBL": (U32, [U32, U32, U32, U32, C.c_int, C.c_int, C.POINTER(PBR_WorkUnit), U32]),
+    "PBR_ExchangeRanges": (C.c_int, [VP, VP, VP, U32, VP, U32]),
+    "PBR_UnitByteRange": (C.c_int, [C.POINTER(PBR_IBLMaps), C.POINTER(PBR_WorkUnit), C.POINTER(TexP), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "PBR_GatherUnits": (C.c_int64, [VP, VP, C.c_int, C.c_int, C.c_int, C.POINTER(PBR_IBLMaps), U32, U32]),
+    "PBR_BandRows": (None, [U32, C.c_int, C.c_int, C.POINTER(U32), C.POINTER(U32)]),
+    "PBR_GatherBands": (C.c_int64, [VP, VP, C.c_int, C.c_int, C.c_int, TexP]),
     "PBR_FillGlobals": (None, [C.POINTER(PBR_Globals), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_float, C.c_float, U32]),
     "PBR_MakeGBuffer": (None, [C.POINTER(PBR_GBuffer), U32, U32, C.c_int]), "PBR_DestroyGBuffer": (None, [C.POINTER(PBR_GBuffer)]),
@@ -315,3 +325,48 @@ def partition(specular_size, min_size, irradiance_size, env_size, world, rank):
     m = L.PBR_PartitionIBL(specular_size, min_size, irradiance_size, env_size, world, rank, arr, n)
     assert m == n
     return arr, n
+
+
+# ---- RCCL bootstrap for tests / bench.py (the library itself never creates a communicator: include/pbr_host.h) ----
+class NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+_RCCL = None
+
+
+def rccl():
+    """librccl as libgpu_hip.so sees it (same SONAME: one copy per process)."""
+    global _RCCL
+    if _RCCL is None:
+        lib()                                             # loads libgpu_hip.so, which pulls librccl.so.1 in
+        R = C.CDLL("librccl.so.1")
+        R.ncclGetUniqueId.argtypes = [C.POINTER(NcclUniqueId)]; R.ncclGetUniqueId.restype = C.c_int
+        R.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, NcclUniqueId, C.c_int]; R.ncclCommInitRank.restype = C.c_int
+        R.ncclCommDestroy.argtypes = [C.c_void_p]; R.ncclCommDestroy.restype = C.c_int
+        R.ncclGetErrorString.argtypes = [C.c_int]; R.ncclGetErrorString.restype = C.c_char_p
+        _RCCL = R
+    return _RCCL
+
+
+def rccl_unique_id():
+    uid = NcclUniqueId()
+    rc = rccl().ncclGetUniqueId(C.byref(uid))
+    if rc != 0:
+        raise RuntimeError("ncclGetUniqueId: " + rccl().ncclGetErrorString(rc).decode())
+    return C.string_at(C.byref(uid), 128)              # (a c_char array read as bytes stops at the first NUL)
+
+
+def rccl_comm_init(world, rank, unique_id: bytes):
+    """ncclCommInitRank -> opaque communicator handle (c_void_p) for PBR_GatherUnits / PBR_GatherBands / PBR_ExchangeRanges."""
+    uid = NcclUniqueId()
+    C.memmove(C.byref(uid), unique_id, 128)
+    comm = C.c_void_p()
+    rc = rccl().ncclCommInitRank(C.byref(comm), int(world), uid, int(rank))
+    if rc != 0:
+        raise RuntimeError("ncclCommInitRank: " + rccl().ncclGetErrorString(rc).decode())
+    return comm
+
+
+def rccl_comm_destroy(comm):
+    rccl().ncclCommDestroy(comm)
