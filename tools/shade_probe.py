@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Time K5 (IBL mode, RGBA16F target) on the C3 spheres frame (1920x1080) and on a temple frame (default 3840x2160; the C5
+scene at a quarter of its pixels), and compare both against the oracle on a few rows.
+   python3 tools/shade_probe.py [temple_w temple_h]      (under rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES for instruction counts)"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vulkan-pbr-renderer_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from pbrhip import synth  # noqa: E402
+
+TW, TH = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
+scenes = [("spheres 1920x1080", synth.synth_gbuffer_spheres(1920, 1080)),
+          (f"temple {TW}x{TH}", synth.synth_gbuffer_temple(TW, TH, workers=min(16, os.cpu_count() or 1)))]
+import pbrhip  # noqa: E402
+import pbr_oracle as O  # noqa: E402
+
+L = pbrhip.init(0)
+L.GPUX_EnableOpTiming(1)
+env = synth.synth_env(64, seed=0x5EED00AA)
+env_tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, 64, 64, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+maps = pbrhip.PBR_IBLMaps()
+L.PBR_MakeIBLMaps(C.byref(maps), 32, 256, 256)
+L.PBR_GenIrradianceMap(env_tex, maps.irradiance_map); L.PBR_GenPrefilteredEnvMap(env_tex, maps.tex_specular_env_map, 16); L.PBR_GenBRDFIntegrationMap(maps.brdf_lut)
+irr = pbrhip.read_mip(maps.irradiance_map, 0)
+n = maps.tex_specular_env_map.contents.mip_level_count
+pyr = np.concatenate([pbrhip.read_mip(maps.tex_specular_env_map, m).ravel() for m in range(n)])
+lut = pbrhip.read_mip(maps.brdf_lut, 0).view(np.uint16)
+for name, gbd in scenes:
+    H, W = gbd["depth"].shape
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), W, H, pbrhip.Format_RGBA16F)
+    for nm, key in (("base_color", "base"), ("normal", "normal"), ("orm", "orm"), ("emissive", "emissive"), ("depth", "depth")):
+        pbrhip.upload_mip(getattr(gb, nm), 0, gbd[key])
+    gb32 = pbrhip.PBR_GBuffer(gb.base_color, gb.normal, gb.orm, gb.emissive, gb.depth, pbrhip.make_texture(pbrhip.Format_RGBA32F, W, H, pbrhip.TextureFlag_RenderTarget))
+    lp = L.PBR_MakeLightingPass(C.byref(gb), C.byref(maps), W, H); lp32 = L.PBR_MakeLightingPass(C.byref(gb32), C.byref(maps), W, H)
+    glob = pbrhip.fill_globals(gbd["cam_pos"], aspect=W / H)
+    g = L.GPU_MakeGraph()
+    ms = []
+    for it in range(12):
+        L.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
+        L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+        ms += [L.GPUX_GraphTimedOpMs(g, i) for i in range(L.GPUX_GraphTimedOpCount(g)) if L.GPUX_GraphTimedOpName(g, i).decode() == "K5.shade"]
+    k = float(np.median(ms[2:]))
+    rows = (H // 7, H // 2, H - H // 7)
+    for y in rows:
+        L.PBR_RecordLightingPass(lp32, g, C.byref(glob), y, y + 1)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    got = pbrhip.read_mip(gb32.lighting_result, 0)
+    og = O.OrcGlobals.from_buffer_copy(bytes(glob))
+    worst = 0.0
+    for y in rows:
+        want = O.shade(og, gbd["base"], gbd["normal"], gbd["orm"], gbd["emissive"], gbd["depth"], flags=O.SHADE_IBL, irradiance_cube=irr,
+                       prefiltered_pyr=pyr, prefiltered_size=256, lut_half=lut, region=(0, W, y, y + 1))[y]
+        e = np.abs(got[y, :, :3].astype(np.float64) - want[:, :3]) / np.maximum(np.abs(want[:, :3]), 1e-2)
+        worst = max(worst, float(e.max()))
+    print(f"{name}: K5 {k * 1e3:.1f} us  {W * H / k / 1e6:.1f} Gpixel/s  {28.0 * W * H / k / 1e6:.0f} GB/s ({28.0 * W * H / k / 1e6 / 80:.1f} % of 8 TB/s)   "
+          f"max rel err vs oracle rows {worst:.2e}", flush=True)
+    L.GPU_DestroyGraph(g); L.PBR_DestroyLightingPass(lp); L.PBR_DestroyLightingPass(lp32); L.GPU_DestroyTexture(gb32.lighting_result)
+    L.PBR_DestroyGBuffer(C.byref(gb))
+L.GPU_WaitUntilIdle(); L.GPU_Deinit()

@@ -1514,7 +1514,9 @@ GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
     // submitted while another one is still in flight (main.cpp:49-51, 91-99 keeps two) starts after everything enqueued so far on
     // the previous graph's stream -- its kernels, lazily built sampler twins, and any exchange the caller appended through
     // GPUX_GraphStream.  Side streams fork from g->stream, so they inherit the dependency.
-    if (G.last_submitted && G.last_submitted != g) {
+    static int order_on = -1;                                     // PBR_GRAPH_ORDER=0: diagnostic only (shows that the ordering test can fail)
+    if (order_on < 0) { const char* e = getenv("PBR_GRAPH_ORDER"); order_on = e ? atoi(e) : 1; }
+    if (order_on && G.last_submitted && G.last_submitted != g) {
         GPU_Graph* prev = G.last_submitted;
         if (!prev->order_ev) HIP_OK(hipEventCreateWithFlags(&prev->order_ev, hipEventDisableTiming));
         HIP_OK(hipEventRecord(prev->order_ev, prev->stream));

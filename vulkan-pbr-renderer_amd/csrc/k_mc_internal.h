@@ -20,17 +20,16 @@ __device__ __forceinline__ f3 tap_rgb(__amdgpu_buffer_rsrc_t rs, int voff, int s
     return mk3(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z));
 }
 
-// "cells" layout: for every tap position (face, j0, i0), i0/j0 in [0, n], the 2x2 RGB footprint
-// {t00, t10, t01, t11} stored contiguously (48 B) -> three 16-byte loads serve a whole bilinear fetch.
+// "cells" layout (pbr_device.h, cells_bilerp): for every tap position (face, j0, i0), i0/j0 in [0, n], the 2x2 RGB footprint in
+// coefficient form {t00, t10 - t00, t01, t11 - t01}, 48 contiguous bytes -> three 16-byte loads and 12 instructions per fetch.
 typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void taps_cells(__amdgpu_buffer_rsrc_t rc, int voff, f3& t00, f3& t10, f3& t01, f3& t11) {
+__device__ __forceinline__ f3 fetch_cells(__amdgpu_buffer_rsrc_t rc, int voff, float a, float b) {
     u32x4c A = __builtin_amdgcn_raw_buffer_load_b128(rc, voff, 0, 0);
     u32x4c Bq = __builtin_amdgcn_raw_buffer_load_b128(rc, voff + 16, 0, 0);
     u32x4c Cq = __builtin_amdgcn_raw_buffer_load_b128(rc, voff + 32, 0, 0);
-    t00 = mk3(__uint_as_float(A.x), __uint_as_float(A.y), __uint_as_float(A.z));
-    t10 = mk3(__uint_as_float(A.w), __uint_as_float(Bq.x), __uint_as_float(Bq.y));
-    t01 = mk3(__uint_as_float(Bq.z), __uint_as_float(Bq.w), __uint_as_float(Cq.x));
-    t11 = mk3(__uint_as_float(Cq.y), __uint_as_float(Cq.z), __uint_as_float(Cq.w));
+    return cells_bilerp(make_float4(__uint_as_float(A.x), __uint_as_float(A.y), __uint_as_float(A.z), __uint_as_float(A.w)),
+                        make_float4(__uint_as_float(Bq.x), __uint_as_float(Bq.y), __uint_as_float(Bq.z), __uint_as_float(Bq.w)),
+                        make_float4(__uint_as_float(Cq.x), __uint_as_float(Cq.y), __uint_as_float(Cq.z), __uint_as_float(Cq.w)), a, b);
 }
 
 // one sample: direction L -> bilinear RGB of the bordered level behind `rs`
@@ -44,20 +43,18 @@ __device__ __forceinline__ f3 sample_bordered(__amdgpu_buffer_rsrc_t rs, f3 L, f
     float u = fmaf(sc, h, off);                                  // s*n - 0.5 + 1 (bordered), in [0.5, n + 0.5]
     float v = fmaf(tc, h, off);
     float a = __builtin_amdgcn_fractf(u), b = __builtin_amdgcn_fractf(v);
-    f3 t00, t10, t01, t11;
     if (CELLS) {
         // Cell byte offset in fp32: cells exist for n <= 512 only, so face*nc + j0, the cell index (< 6*513^2 < 2^24) and
         // 48*cell (= 16 * an integer < 2^24) are all exact -- six FMA-rate instructions instead of three conversions and three
         // integer multiplies (v_mul_lo_u32 / v_mad_u64_u32 issue at 1.45x / 1.7x the cost of an FMA here, tools/ubench_valu.hip).
         float ncf = (float)(nb - 1);                             // n + 1 tap positions per edge
         float cellf = fmaf(fmaf(fid, ncf, floorf(v)), ncf, floorf(u));
-        taps_cells(rs, (int)(cellf * 48.0f), t00, t10, t01, t11);
-    } else {
-        int i0 = (int)u, j0 = (int)v, face = (int)fid;
-        int voff = ((face * nb + j0) * nb + i0) << 4;
-        t00 = tap_rgb(rs, voff, 0); t10 = tap_rgb(rs, voff + 16, 0);
-        t01 = tap_rgb(rs, voff, row_bytes); t11 = tap_rgb(rs, voff + 16, row_bytes);
+        return fetch_cells(rs, (int)(cellf * 48.0f), a, b);
     }
+    int i0 = (int)u, j0 = (int)v, face = (int)fid;
+    int voff = ((face * nb + j0) * nb + i0) << 4;
+    f3 t00 = tap_rgb(rs, voff, 0), t10 = tap_rgb(rs, voff + 16, 0);
+    f3 t01 = tap_rgb(rs, voff, row_bytes), t11 = tap_rgb(rs, voff + 16, row_bytes);
     f3 r;
     r.x = lerp_fma(lerp_fma(t00.x, t10.x, a), lerp_fma(t01.x, t11.x, a), b);
     r.y = lerp_fma(lerp_fma(t00.y, t10.y, a), lerp_fma(t01.y, t11.y, a), b);

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_lightgrid_sweep(uint2* __restrict__ img
     //      counter in LDS; wave 3 (no channel to sweep) polls it and streams every chunk all three have finished back to HBM
     //      (:72 only voxels whose old alpha < 0.5; alpha itself is unchanged).  The counter reaches 3 * kChunks unconditionally,
     //      so wave 3 always leaves its loop.
-    volatile int* progress = (volatile int*)(tile + kLen * kPitch);
+    int* progress = (int*)(tile + kLen * kPitch);
     if (wave < 3) {
         unsigned cv[kChunk], ca[kChunk], nv[kChunk], na[kChunk];
         if (sweeper) {
@@ -176,14 +176,16 @@ __global__ __launch_bounds__(256) void k_lightgrid_sweep(uint2* __restrict__ img
 #pragma unroll
                 for (int j = 0; j < kChunk; ++j) { cv[j] = nv[j]; ca[j] = na[j]; }
             }
-            // LDS operations of one wave complete in order: the counter bump lands after this chunk's tile writes
-            if (lane == 0) atomicAdd((int*)progress, 1);
+            // release: this chunk's tile writes are ordered before the counter bump for the compiler as well as the hardware
+            // (LDS operations of one wave complete in order; the release keeps the stores from being sunk below the atomic)
+            if (lane == 0) __hip_atomic_fetch_add(progress, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     } else {
 #pragma unroll 1
         for (int done = kChunks - 1; done >= 0; --done) {
             const int need = 3 * (kChunks - done);
-            while (*progress < need) __builtin_amdgcn_s_sleep(2);
+            // acquire: the tile loads below may not be hoisted above the poll that licenses them
+            while (__hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(2);
             if (g.pair_stores) {
                 // 16 B per lane.  Occupied voxels still hold their loaded bits in the tile, so storing a pair whole only rewrites
                 // identical data where the shader would have skipped the store (:72); this keeps wave 3 (the only storing
