@@ -5,14 +5,25 @@
 // render.cpp:607-613 (whose 6 z-slices all write the same texel; computed once here).
 //
 // The quadrature is numerically ill-conditioned at low roughness: the Beckmann lobe is a function of
-// 1 - N.H, so a one-ulp change of H moves a sample's weight by percents.  To stay texel-for-texel
-// comparable the kernel keeps the shader's operation order for everything that feeds N.H (Rotate,
-// normalize: separately rounded fp32, correctly rounded divide / sqrt), takes sample angles and the
-// per-column view angle from host tables, and evaluates acos/tan/exp/pow with the device libm.
-// One thread per texel, sequential sample loop (same summation order as the shader).
+// 1 - N.H, so a one-ulp change of H moves a sample's weight by percents.  Everything that feeds N.H
+// therefore keeps the shader's operation order with correctly rounded results (Rotate, normalize; sample
+// angles and the per-column view angle come from host tables); what follows N.H is continuous and is
+// evaluated in the cheapest accurate form: tan^2(acos n) = (1 - n^2) / n^2 with 1 - n^2 from one FMA
+// (a relative error of 2^-24 where the libm route also carries ~2 ulp), v_exp_f32, x^5 by three
+// multiplications, reciprocals instead of divisions.
+//
+// Work decomposition (north_star: wavefront-shuffle reductions): the sample directions L_i depend on i
+// only, so a 512-thread workgroup first builds them once in LDS (64 KB, the shader's two Rotate() calls
+// per sample, bit for bit) and then walks 128 texels of one row: each wave owns a texel at a time, its
+// 64 lanes take samples l, l + 64, ... and the two sums are folded with a fixed xor-butterfly
+// (deterministic; a row-sharded dispatch equals a full one bit for bit).  512 workgroups for a 256^2
+// map: 16 waves per CU.
 #include "pbr_device.h"
 #include "pbr_kernels.h"
 #include <hip/hip_fp16.h>
+
+#define LUT_BLOCK 512
+#define LUT_TEXELS 128          // texels of one row per workgroup
 
 // EXACT: Rotate() of gen_brdf_integration_map.glsl:61-64
 __device__ __forceinline__ f3 rotate_exact(f3 v, f3 n, float c, float s) {
@@ -23,48 +34,68 @@ __device__ __forceinline__ f3 rotate_exact(f3 v, f3 n, float c, float s) {
     return add3(add3(a, b), cc);
 }
 
-__device__ __forceinline__ float beckmann_dev(float ndoth, float m) {
-    float m2 = m * m;
-    float a = tanf(acosf(ndoth));
-    float n2 = ndoth * ndoth;
-    return expf(-(a * a) / m2) / (PBR_PI * m2 * n2 * n2);
-}
-
-__global__ __launch_bounds__(64) void k_brdf_lut(void* __restrict__ out, int fmt, int size, int nsamples,
-                                                 const float4* __restrict__ angles, const float2* __restrict__ view_cs,
-                                                 int y0, int rows) {
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= rows * size) return;
-    int x = id % size, y = y0 + id / size;
-    float NdotV = ((float)x + 0.5f) / (float)size;           // :143, :154
-    float rough = ((float)y + 0.5f) / (float)size;           // :155
+__global__ __launch_bounds__(LUT_BLOCK) void k_brdf_lut(void* __restrict__ out, int fmt, int size, int nsamples,
+                                                        const float4* __restrict__ angles, const float2* __restrict__ view_cs,
+                                                        int y0, int groups_per_row) {
+    extern __shared__ __attribute__((aligned(16))) float4 Ltab[];        // L_i (xyz), i < nsamples
     const f3 N = mk3(0.0f, 0.0f, 1.0f);
     const f3 X = mk3(1.0f, 0.0f, 0.0f);
-    float2 vcs = view_cs[x];
-    f3 V = rotate_exact(N, X, vcs.x, vcs.y);                 // :160
-    float dw = 2 * PBR_PI / (float)nsamples;                 // :168
-    float scale = 0.0f, bias = 0.0f;
-    for (int i = 0; i < nsamples; ++i) {
+    for (int i = threadIdx.x; i < nsamples; i += LUT_BLOCK) {
         float4 a = angles[i];
         f3 L = rotate_exact(N, X, a.x, a.y);                 // :177
         L = rotate_exact(L, N, a.z, a.w);                    // :178
-        f3 H = normalize3(add3(L, V));                       // :179
-        float NdotL = dot3(N, L);
-        float NdotH = dot3(N, H);
-        float VdotH = dot3(V, H);
-        float D = beckmann_dev(NdotH, rough);                // :192
-        float G = fminf(1.0f, fminf(2.0f * NdotH * NdotV / VdotH, 2.0f * NdotH * NdotL / VdotH));   // :193
-        float Fc = powf(1.0f - VdotH, 5.0f);                 // :196
-        scale += D * G * (1 - Fc) * dw / (4.0f * NdotV);     // :198
-        bias += D * G * (0 + Fc) * dw / (4.0f * NdotV);      // :199
+        Ltab[i] = make_float4(L.x, L.y, L.z, 0.0f);
     }
-    size_t o = (size_t)y * size + x;
-    if (fmt == PBRK_FMT_RG16F) {
-        ((__half2*)out)[o] = __halves2half2(__float2half_rn(scale), __float2half_rn(bias));
-    } else if (fmt == PBRK_FMT_RG32F) {
-        ((float2*)out)[o] = make_float2(scale, bias);
-    } else {
-        ((float4*)out)[o] = make_float4(scale, bias, 0.0f, 1.0f);   // :209
+    __syncthreads();
+
+    const int y = y0 + (int)blockIdx.x / groups_per_row;
+    const int x_base = ((int)blockIdx.x % groups_per_row) * LUT_TEXELS;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float rough = ((float)y + 0.5f) / (float)size;     // :155
+    const float m2 = rough * rough;
+    const float k_exp = -1.4426950408889634f / m2;           // exp(-a2 / m2) = 2^(a2 * k_exp)
+    const float dw = 2 * PBR_PI / (float)nsamples;           // :168
+    for (int tx = wave; tx < LUT_TEXELS; tx += LUT_BLOCK / 64) {
+        const int x = x_base + tx;
+        if (x >= size) break;                                // wave-uniform
+        const float NdotV = ((float)x + 0.5f) / (float)size; // :143, :154
+        const float2 vcs = view_cs[x];
+        const f3 V = rotate_exact(N, X, vcs.x, vcs.y);       // :160  = (0, -sin, cos)
+        const float kw = dw * __builtin_amdgcn_rcpf(4.0f * NdotV);
+        float scale = 0.0f, bias = 0.0f;
+        for (int i = lane; i < nsamples; i += 64) {
+            const float4 Lq = Ltab[i];
+            const f3 L = mk3(Lq.x, Lq.y, Lq.z);
+            const f3 H = normalize3_nr(add3(L, V));          // :179 (correctly rounded: feeds N.H)
+            const float NdotL = dot3(N, L);
+            const float NdotH = dot3(N, H);
+            const float VdotH = dot3(V, H);
+            // :34-39 Beckmann: tan^2(acos n) = (1 - n^2) / n^2
+            const float n2 = NdotH * NdotH;
+            const float rn2 = __builtin_amdgcn_rcpf(n2);
+            const float a2 = fmaf(-NdotH, NdotH, 1.0f) * rn2;
+            const float D = __builtin_amdgcn_exp2f(a2 * k_exp) * (rn2 * rn2) * __builtin_amdgcn_rcpf(PBR_PI * m2);
+            // :57-59 Mikkelsen
+            const float t2 = 2.0f * NdotH * __builtin_amdgcn_rcpf(VdotH);
+            const float G = fminf(1.0f, fminf(t2 * NdotV, t2 * NdotL));      // :193
+            const float q = 1.0f - VdotH, q2 = q * q;
+            const float Fc = q2 * q2 * q;                    // :196 pow(1 - VdotH, 5.)
+            const float w = D * G * kw;                      // :198-199
+            scale = fmaf(w, 1.0f - Fc, scale);
+            bias = fmaf(w, Fc, bias);
+        }
+        // fixed xor-butterfly over the 64 lanes
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            scale += __shfl_xor(scale, o);
+            bias += __shfl_xor(bias, o);
+        }
+        if (lane == 0) {
+            size_t o = (size_t)y * size + x;
+            if (fmt == PBRK_FMT_RG16F) ((__half2*)out)[o] = __halves2half2(__float2half_rn(scale), __float2half_rn(bias));
+            else if (fmt == PBRK_FMT_RG32F) ((float2*)out)[o] = make_float2(scale, bias);
+            else ((float4*)out)[o] = make_float4(scale, bias, 0.0f, 1.0f);   // :209
+        }
     }
 }
 
@@ -73,9 +104,12 @@ extern "C" int pbrk_brdf_lut(void* out, int out_format, int size, int nsamples, 
     if (!out || !angles4 || !view_cs || size < 1 || nsamples < 1) return PBRK_E_ARG;
     if (y0 < 0 || y1 > size || y0 >= y1) return PBRK_E_ARG;
     if (out_format != PBRK_FMT_RG16F && out_format != PBRK_FMT_RG32F && out_format != PBRK_FMT_RGBA32F) return PBRK_E_FORMAT;
-    int rows = y1 - y0;
-    int total = rows * size;
-    hipLaunchKernelGGL(k_brdf_lut, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream,
-                       out, out_format, size, nsamples, (const float4*)angles4, (const float2*)view_cs, y0, rows);
+    size_t lds = (size_t)nsamples * 16;
+    if (lds > 150 * 1024) return PBRK_E_ARG;                 // sample directions live in LDS (9600 samples at most)
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_brdf_lut, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    int groups_per_row = (size + LUT_TEXELS - 1) / LUT_TEXELS;
+    hipLaunchKernelGGL(k_brdf_lut, dim3((unsigned)((y1 - y0) * groups_per_row)), dim3(LUT_BLOCK), lds, (hipStream_t)stream,
+                       out, out_format, size, nsamples, (const float4*)angles4, (const float2*)view_cs, y0, groups_per_row);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }

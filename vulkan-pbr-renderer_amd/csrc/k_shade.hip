@@ -530,19 +530,6 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
 // fetches, composition) is continuous and uses FMAs, 1-ulp reciprocals and the fast unorm8 decode.
 // All texture reads go through range-checked buffer loads with 32-bit offsets (no 64-bit address arithmetic, no clamps).
 // ==========================================================================================
-__device__ __forceinline__ float rcp_nr(float d) {
-    float r = __builtin_amdgcn_rcpf(d);
-    return fmaf(fmaf(-d, r, 1.0f), r, r);
-}
-__device__ __forceinline__ float sqrt_nr(float x) {
-    float y = __builtin_amdgcn_rsqf(x);
-    float s = x * y, h = 0.5f * y;
-    return fmaf(fmaf(-s, s, x), h, s);
-}
-__device__ __forceinline__ f3 normalize3_nr(f3 a) {
-    SharedRcp e; e.d = sqrt_nr(dot3(a, a)); e.r = rcp_nr(e.d);
-    return mk3(div_by(a.x, e), div_by(a.y, e), div_by(a.z, e));
-}
 typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 bl4(__amdgpu_buffer_rsrc_t r, int off) {
     u32x4s v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);

@@ -46,6 +46,24 @@ __device__ __forceinline__ f3 normalize3_shared(f3 a) {
     return mk3(div_by(a.x, e), div_by(a.y, e), div_by(a.z, e));
 }
 
+// Correctly rounded reciprocal / square root / normalize through v_rcp_f32 / v_rsq_f32 (1 ulp) and ONE Newton step in FMAs:
+// the corrected value carries a relative error of ~1e-14 before its final rounding, so the result is RN(1/d) / RN(sqrt(x))
+// unless the exact value lies that close to a rounding boundary (about 2e-7 of all operands; the result is then one ulp off).
+// 3 and 5 instructions instead of the ~10 / ~12 of the IEEE expansions.  Used where bit-equality with a CPU evaluation matters
+// for conditioning, not for a branch (k_shade_fast, k_brdf_lut); the bit-exact kernels keep true divisions.
+__device__ __forceinline__ float rcp_nr(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float sqrt_nr(float x) {
+    float y = __builtin_amdgcn_rsqf(x);
+    float s = x * y, h = 0.5f * y;
+    return fmaf(fmaf(-s, s, x), h, s);
+}
+__device__ __forceinline__ f3 normalize3_nr(f3 a) {
+    SharedRcp e; e.d = sqrt_nr(dot3(a, a)); e.r = rcp_nr(e.d);
+    return mk3(div_by(a.x, e), div_by(a.y, e), div_by(a.z, e));
+}
 // EXACT: CubemapSampleDirFromFaceUV (reference shaders/gen_prefiltered_env_map.glsl:11-66):
 // texel (ix,iy) of an n*n face -> unit direction through the texel centre.
 __device__ __forceinline__ f3 face_texel_dir(int face, int ix, int iy, int n) {
