@@ -388,7 +388,7 @@ def main():
     extra = {}
     if rank == 0 and not args.no_shade:
         try:
-            extra["shade"] = shade_bench(L, pbrhip, maps, world)
+            extra["shade"] = shade_bench(L, pbrhip, env_tex, world)
         except Exception as e:      # the headline number must not depend on the extra
             extra["shade_error"] = repr(e)
         try:
@@ -474,11 +474,17 @@ def main():
         dist.destroy_process_group()
 
 
-def shade_bench(L, pbrhip, maps, world, frames=20):
-    """C3: 1920x1080 synthetic metal-rough-spheres G-buffer through the lighting pass (K5), IBL maps from this run."""
+def shade_bench(L, pbrhip, env_tex, world, frames=20):
+    """C3: 1920x1080 synthetic metal-rough-spheres G-buffer through the lighting pass (K5); IBL maps at the reference's sizes
+    (render.cpp:794-796: 32^2 irradiance, 256^2 LUT, 256^2 prefiltered cube with mips down to 16^2) from this run's environment."""
     from pbrhip import synth
     W, H = 1920, 1080
     gbd = synth.synth_gbuffer_spheres(W, H)
+    maps = pbrhip.PBR_IBLMaps()
+    L.PBR_MakeIBLMaps(C.byref(maps), 32, 256, 256)
+    L.PBR_GenIrradianceMap(env_tex, maps.irradiance_map)
+    L.PBR_GenPrefilteredEnvMap(env_tex, maps.tex_specular_env_map, 16)
+    L.PBR_GenBRDFIntegrationMap(maps.brdf_lut)
     gb = pbrhip.PBR_GBuffer()
     L.PBR_MakeGBuffer(C.byref(gb), W, H, pbrhip.Format_RGBA16F)
     for name, arr in (("base_color", gbd["base"]), ("normal", gbd["normal"]), ("orm", gbd["orm"]),
@@ -503,7 +509,7 @@ def shade_bench(L, pbrhip, maps, world, frames=20):
            "mpixels_per_s_wall": W * H * frames / wall / 1e6,
            "roofline": {"kernel": "K5.shade", "bound": "hbm", "achieved": byt / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": byt / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}}
-    L.GPU_DestroyGraph(g); L.PBR_DestroyLightingPass(lp); L.PBR_DestroyGBuffer(C.byref(gb))
+    L.GPU_DestroyGraph(g); L.PBR_DestroyLightingPass(lp); L.PBR_DestroyGBuffer(C.byref(gb)); L.PBR_DestroyIBLMaps(C.byref(maps))
     return res
 
 

@@ -25,6 +25,41 @@ __global__ __launch_bounds__(256) void k_mip_level(const float4* __restrict__ sr
     dst[((size_t)f * nd + y) * nd + x] = o;
 }
 
+// Two levels per launch: a thread forms a 2x2 block of level l from a 4x4 block of level l-1 (four 64-byte row segments) and,
+// from those four results, the texel of level l+1 they cover -- exactly the values and the operation order the next launch
+// would have read back from HBM, so the chain stays bit-identical while level l is never re-read (671 -> 562 MB at W = 2048,
+// half the launches).  Lanes of a wave cover 64 adjacent 2x2 blocks of a row pair: 128 contiguous bytes per lane pair on the
+// read side, 32-byte stores for level l and 16-byte stores for level l+1.
+__device__ __forceinline__ float4 box4(float4 a, float4 b, float4 c, float4 d) {
+    float4 o;
+    o.x = (((a.x + b.x) + c.x) + d.x) * 0.25f;
+    o.y = (((a.y + b.y) + c.y) + d.y) * 0.25f;
+    o.z = (((a.z + b.z) + c.z) + d.z) * 0.25f;
+    o.w = (((a.w + b.w) + c.w) + d.w) * 0.25f;
+    return o;
+}
+__global__ __launch_bounds__(256) void k_mip_level2(const float4* __restrict__ src, float4* __restrict__ dst1, float4* __restrict__ dst2,
+                                                    int ns, int n1, int n2) {
+    int x2 = blockIdx.x * 64 + (threadIdx.x & 63);           // texel of level l+1
+    int y2 = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int f = blockIdx.z;
+    if (x2 >= n2 || y2 >= n2) return;
+    const float4* p = src + ((size_t)f * ns + 4 * y2) * ns + 4 * x2;
+    float4 r[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float4* q0 = p + (size_t)(2 * j) * ns;
+        const float4* q1 = q0 + ns;
+        float4 a0 = q0[0], b0 = q0[1], a1 = q0[2], b1 = q0[3];
+        float4 c0 = q1[0], d0 = q1[1], c1 = q1[2], d1 = q1[3];
+        r[2 * j] = box4(a0, b0, c0, d0);
+        r[2 * j + 1] = box4(a1, b1, c1, d1);
+    }
+    float4* o1 = dst1 + ((size_t)f * n1 + 2 * y2) * n1 + 2 * x2;
+    o1[0] = r[0]; o1[1] = r[1]; o1[n1] = r[2]; o1[n1 + 1] = r[3];
+    dst2[((size_t)f * n2 + y2) * n2 + x2] = box4(r[0], r[1], r[2], r[3]);
+}
+
 // ------------------------------------------------------------------------------------------
 // Apron build.  Edge adjacency of the Vulkan cube faces (table in gen_prefiltered_env_map.glsl:12-23),
 // per face and edge {left i=-1, right i=n, top j=-1, bottom j=n}: neighbour face and how its
@@ -83,9 +118,63 @@ __global__ __launch_bounds__(256) void k_border_level(const float4* __restrict__
 // ------------------------------------------------------------------------------------------
 // K4a: out(face, y, x) = bilinear(src level, R(face, x, y)); 16 B coalesced store per lane.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prefilter_copy(const float4* __restrict__ src, int n_src,
+// The lookup is bit-identical to a scalar CPU evaluation (a tap weight next to a 5e4:1 sun texel leaves no room): the
+// direction, its cube projection and the weights keep the shader's operation order with correctly rounded results, through the
+// Newton-corrected v_rsq / v_rcp sequences of pbr_device.h; taps come through range-checked buffer loads (32-bit offsets).
+typedef unsigned int u32x4k __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(__amdgpu_buffer_rsrc_t r, int off) {
+    u32x4k v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__global__ __launch_bounds__(256) void k_prefilter_copy(const float4* __restrict__ src, int n_src, unsigned src_bytes,
                                                         float4* __restrict__ out, int size,
                                                         int face0, int y0, int rows) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int yr = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int f = face0 + blockIdx.z;
+    if (x >= size || yr >= rows) return;
+    int y = y0 + yr;
+    // CubemapSampleDirFromFaceUV (gen_prefiltered_env_map.glsl:11-66), power-of-two sizes: x / n == x * (1/n) exactly
+    float rn = 1.0f / (float)size;
+    float sc0 = 2 * (((float)x + 0.5f) * rn - 0.5f), tc0 = 2 * (((float)y + 0.5f) * rn - 0.5f);
+    f3 r;
+    switch (f) {
+    case 0: r = mk3(1.0f, -tc0, -sc0); break;
+    case 1: r = mk3(-1.0f, -tc0, sc0); break;
+    case 2: r = mk3(sc0, 1.0f, tc0); break;
+    case 3: r = mk3(sc0, -1.0f, -tc0); break;
+    case 4: r = mk3(sc0, -tc0, 1.0f); break;
+    default: r = mk3(-sc0, -tc0, -1.0f); break;
+    }
+    const f3 R = normalize3_nr(r);
+    // textureLod(env, R, 1.0): face selection in hardware, s = (0.5 sc) / |ma| + 0.5, u = s n - 0.5
+    const float fid = __builtin_amdgcn_cubeid(R.x, R.y, R.z);
+    const float sc = __builtin_amdgcn_cubesc(R.x, R.y, R.z), tc = __builtin_amdgcn_cubetc(R.x, R.y, R.z);
+    SharedRcp rma; rma.d = 0.5f * fabsf(__builtin_amdgcn_cubema(R.x, R.y, R.z)); rma.r = rcp_nr(rma.d);
+    const float s = div_by(0.5f * sc, rma) + 0.5f, t = div_by(0.5f * tc, rma) + 0.5f;
+    const float nf = (float)n_src;
+    const float u = s * nf - 0.5f, v = t * nf - 0.5f;
+    const float fu = floorf(u), fv = floorf(v);
+    const float a = u - fu, b = v - fv;
+    const float nbf = nf + 2.0f;
+    // bordered texel index (face * nb + j0) * nb + i0 with i0 = floor(u) + 1 in [0, n]: exact in fp32 for n <= 1022
+    const int off = (int)(fmaf(fmaf(fid, nbf, fv + 1.0f), nbf, fu + 1.0f) * 16.0f);
+    const int row = (n_src + 2) * 16;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)src_bytes, 0x00020000);
+    const float4 t00 = ld4(rs, off), t10 = ld4(rs, off + 16), t01 = ld4(rs, off + row), t11 = ld4(rs, off + row + 16);
+    float4 o;
+    o.x = lerp_fma(lerp_fma(t00.x, t10.x, a), lerp_fma(t01.x, t11.x, a), b);
+    o.y = lerp_fma(lerp_fma(t00.y, t10.y, a), lerp_fma(t01.y, t11.y, a), b);
+    o.z = lerp_fma(lerp_fma(t00.z, t10.z, a), lerp_fma(t01.z, t11.z, a), b);
+    o.w = lerp_fma(lerp_fma(t00.w, t10.w, a), lerp_fma(t01.w, t11.w, a), b);
+    typedef float v4n __attribute__((ext_vector_type(4)));
+    v4n ov = {o.x, o.y, o.z, o.w};
+    __builtin_nontemporal_store(ov, (v4n*)&out[((size_t)f * size + y) * size + x]);        // written once, read by a later pass: keep it out of L2
+}
+// general sizes (not a power of two, or a level beyond the fp32 index range): the plain exact path
+__global__ __launch_bounds__(256) void k_prefilter_copy_general(const float4* __restrict__ src, int n_src,
+                                                                float4* __restrict__ out, int size,
+                                                                int face0, int y0, int rows) {
     int x = blockIdx.x * 64 + (threadIdx.x & 63);
     int yr = blockIdx.y * 4 + (threadIdx.x >> 6);
     int f = face0 + blockIdx.z;
@@ -109,7 +198,13 @@ extern "C" int pbrk_mip_chain(void* pyramid, int W, int levels, void* stream) {
     if (!pyramid || W <= 0 || levels < 1 || levels > pbrk_mip_count(W, W)) return PBRK_E_ARG;
     if (W & (W - 1)) return PBRK_E_ARG;    // exact 2:1 chain only
     float4* base = (float4*)pyramid;
-    for (int l = 1; l < levels; ++l) {
+    int l = 1;
+    for (; l + 1 < levels && lvl_size(W, l + 1) >= 2; l += 2) {              // pairs of levels while the second one is at least 2x2
+        int ns = lvl_size(W, l - 1), n1 = lvl_size(W, l), n2 = lvl_size(W, l + 1);
+        hipLaunchKernelGGL(k_mip_level2, dim3((n2 + 63) / 64, (n2 + 3) / 4, 6), dim3(256), 0, (hipStream_t)stream,
+                           (const float4*)(base + pbrk_level_offset(W, l - 1)), base + pbrk_level_offset(W, l), base + pbrk_level_offset(W, l + 1), ns, n1, n2);
+    }
+    for (; l < levels; ++l) {
         int ns = lvl_size(W, l - 1), nd = lvl_size(W, l);
         const float4* src = base + pbrk_level_offset(W, l - 1);
         float4* dst = base + pbrk_level_offset(W, l);
@@ -146,7 +241,13 @@ extern "C" int pbrk_prefilter_copy(const void* src_bordered_level, int n_src, vo
                                    int face0, int face1, int y0, int y1, void* stream) {
     if (!src_bordered_level || !out || n_src < 1 || out_size < 1) return PBRK_E_ARG;
     if (face0 < 0 || face1 > 6 || face0 >= face1 || y0 < 0 || y1 > out_size || y0 >= y1) return PBRK_E_ARG;
-    hipLaunchKernelGGL(k_prefilter_copy, dim3((out_size + 63) / 64, (y1 - y0 + 3) / 4, face1 - face0), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)src_bordered_level, n_src, (float4*)out, out_size, face0, y0, y1 - y0);
+    dim3 grid((out_size + 63) / 64, (y1 - y0 + 3) / 4, face1 - face0);
+    size_t src_bytes = (size_t)6 * (n_src + 2) * (n_src + 2) * 16;
+    if ((out_size & (out_size - 1)) == 0 && n_src <= 1022)
+        hipLaunchKernelGGL(k_prefilter_copy, grid, dim3(256), 0, (hipStream_t)stream,
+                           (const float4*)src_bordered_level, n_src, (unsigned)src_bytes, (float4*)out, out_size, face0, y0, y1 - y0);
+    else
+        hipLaunchKernelGGL(k_prefilter_copy_general, grid, dim3(256), 0, (hipStream_t)stream,
+                           (const float4*)src_bordered_level, n_src, (float4*)out, out_size, face0, y0, y1 - y0);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
