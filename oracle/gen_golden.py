@@ -45,7 +45,14 @@ def main():
         dict(pos=(0, 0, 5), ori=None, fov=75.0, aspect=16 / 9, near=.02, far=1e4, sun=(56.5, 97.0), frame=0),      # main.cpp:18,21,85-88
         dict(pos=(0, -9, 0), ori=None, fov=75.0, aspect=16 / 9, near=.02, far=1e4, sun=(56.5, 97.0), frame=7),     # C3 bench camera
         dict(pos=(3.5, -12.25, 1.75), ori=(0.5, -0.1, 0.2, 0.8), fov=60.0, aspect=4 / 3, near=.1, far=500.0, sun=(20.0, 200.0), frame=100),
+        dict(pos=(0, -30, 6), ori=None, fov=75.0, aspect=16 / 9, near=.02, far=1e4, sun=(56.5, 97.0), frame=3),     # C5 temple camera
     ]
+    rng = np.random.default_rng(0x5EED00C4)                        # seeded random poses: the op order must hold in general position
+    for _ in range(12):
+        poses.append(dict(pos=tuple(float(np.float32(v)) for v in rng.uniform(-40, 40, 3)), ori=tuple(float(v) for v in rng.normal(size=4)),
+                          fov=float(np.float32(rng.uniform(30, 110))), aspect=float(np.float32(rng.uniform(0.5, 2.5))),
+                          near=float(np.float32(rng.uniform(0.01, 1.0))), far=float(np.float32(rng.uniform(100, 2e4))),
+                          sun=(float(np.float32(rng.uniform(0, 90))), float(np.float32(rng.uniform(0, 360)))), frame=int(rng.integers(0, 1000))))
     out = np.zeros((len(poses), 140), np.float32)
     for k, p in enumerate(poses):
         q = p["ori"]

@@ -135,9 +135,8 @@ def test_fill_globals_matches_reference_handmade_math(L, golden_dir):
         g = pbrhip.fill_globals(z["pos"][k], ori, fov, aspect, near, far, (sx, sy), int(frame))
         got = np.frombuffer(bytes(g), np.float32)[:137]
         want = z["globals"][k][:137]
-        scale = np.maximum(np.abs(want).reshape(-1), 1e-3)
-        # matrices: fp32 rounding of a different-but-equivalent op order; the inverse-projection entries are ~250 with 1e-5 abs noise
-        assert np.all(np.abs(got - want) <= 2e-5 * np.maximum(scale, 1.0)), k
+        # bit for bit: same operation order as the reference's math library (world_space_from_clip feeds the sky test)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (k, np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0])
     g0 = pbrhip.fill_globals((0, 0, 5))
     assert np.allclose(list(g0.sun_direction)[:3], (-0.827670276, -0.101625085, -0.551936984), atol=1e-6)
     wfc = np.array(list(g0.world_space_from_clip)).reshape(4, 4)

@@ -7,7 +7,10 @@
  *   render.cpp:680-693             G-buffer + lighting result textures
  *   render.cpp:716-723, :829-871   lighting render pass, pipeline layout, descriptor set
  *   render.cpp:1119-1127           PrepareRenderPass .. Draw(3,1,0,0) .. EndRenderPass
- * Matrix code is written from the standard formulas (column-major, m[col*4+row]), all in fp32.
+ * Matrix code is written from the standard formulas (column-major, m[col*4+row]), all in fp32, in the operation order of the
+ * reference's math library (third_party/HandmadeMath.h v2.0: linear-combination products, cross-product inverse, axis scaled by
+ * 1/sqrt): the block equals the reference's bit for bit on the golden poses (tests/test_host_cpu.py), which matters for
+ * world_space_from_clip -- it feeds the discontinuous sky test of lighting_pass.glsl:708.
  */
 #include "pbr_host.h"
 
@@ -32,8 +35,12 @@ static M4 m4_mul(const M4* a, const M4* b) {        /* a * b */
 
 static M4 m4_translate(float x, float y, float z) { M4 r = m4_identity(); r.m[12] = x; r.m[13] = y; r.m[14] = z; return r; }
 
+/* 4-component dot product as the reference's math library forms it on SSE hardware (its build target): two pairwise sums,
+ * (x x' + y y') + (w w' + z z').  The scalar fallback of that library pairs differently; the renderer never takes it. */
+static float dot4(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + (a[3] * b[3] + a[2] * b[2]); }
+
 static void q_normalize(float q[4]) {
-    float len = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+    float len = sqrtf(dot4(q, q));
     float inv = 1.0f / len;
     for (int i = 0; i < 4; ++i) q[i] *= inv;
 }
@@ -101,8 +108,8 @@ static M4 m4_inverse(const M4* M) {
 }
 
 static M4 m4_rotate_rh(float angle, float ax, float ay, float az) {
-    float len = sqrtf((ax * ax + ay * ay) + az * az);
-    ax /= len; ay /= len; az /= len;
+    float inv = 1.0f / sqrtf((ax * ax + ay * ay) + az * az);          /* the axis is scaled by the reciprocal of its length, not divided */
+    ax *= inv; ay *= inv; az *= inv;
     float s = sinf(angle), c = cosf(angle), k = 1.0f - c;
     M4 r = m4_identity();
     r.m[0] = (ax * ax * k) + c;        r.m[1] = (ax * ay * k) + (az * s); r.m[2] = (ax * az * k) - (ay * s);
@@ -125,7 +132,7 @@ void PBR_FillGlobals(PBR_Globals* g, const float pos[3], const float ori_xyzw[4]
     M4 rot = m4_from_quat(ori);
     M4 tr = m4_translate(pos[0], pos[1], pos[2]);
     M4 world_from_view = m4_mul(&tr, &rot);
-    float dq = ((ori[0] * ori[0] + ori[1] * ori[1]) + ori[2] * ori[2]) + ori[3] * ori[3];
+    float dq = dot4(ori, ori);
     float inv_ori[4] = {-ori[0] / dq, -ori[1] / dq, -ori[2] / dq, ori[3] / dq};
     M4 inv_rot = m4_from_quat(inv_ori);
     M4 inv_tr = m4_translate(pos[0] * -1.0f, pos[1] * -1.0f, pos[2] * -1.0f);
@@ -151,8 +158,11 @@ void PBR_FillGlobals(PBR_Globals* g, const float pos[3], const float ori_xyzw[4]
     memcpy(g->world_space_from_view, world_from_view.m, 64);
     memcpy(g->sun_space_from_world, sun_space_from_world.m, 64);
     memcpy(g->old_clip_space_from_world, clip_from_world.m, 64);              /* frame 0 (render.cpp:985) */
-    /* sun_dir = sun_ori * (0,0,-1,0) (render.cpp:970) */
-    g->sun_direction[0] = -sun_ori.m[8]; g->sun_direction[1] = -sun_ori.m[9]; g->sun_direction[2] = -sun_ori.m[10]; g->sun_direction[3] = 0.0f;
+    /* sun_dir = sun_ori * (0,0,-1,0) (render.cpp:970), as the matrix-vector product forms it: ((c0*0 + c1*0) + c2*(-1)) + c3*0,
+     * which turns a -0 component into +0 */
+    for (int i = 0; i < 3; ++i)
+        g->sun_direction[i] = ((sun_ori.m[i] * 0.0f + sun_ori.m[4 + i] * 0.0f) + sun_ori.m[8 + i] * -1.0f) + sun_ori.m[12 + i] * 0.0f;
+    g->sun_direction[3] = 0.0f;
     g->camera_pos[0] = pos[0]; g->camera_pos[1] = pos[1]; g->camera_pos[2] = pos[2];
     g->frame_idx_mod_59 = (float)(frame_idx % 59);
     g->lightgrid_scale = 1.0f / lightgrid_extent;
