@@ -107,8 +107,23 @@ def cpu_baseline(env, W, spec_size, irr_size, budget_s=15.0):
     total_cp = 6 * spec_size * spec_size
     est_time = total_mc / rate_mc + total_cp / rate_cp
     total_units = total_cp + sum(6 * max(1, spec_size >> m) ** 2 for m in range(1, nm)) + 6 * irr_size * irr_size
+    # the same loops on ONE thread, in the hoisted-table form and in the literal form (the shader's own operation
+    # sequence per sample: two Rotate() calls, acos, tan, exp), on a few rows of mip 2
+    extra_rates = {}
+    try:
+        O.set_threads(1)
+        size2 = max(1, spec_size >> 2)
+        for key, literal, rows1 in (("single_thread", False, 2), ("single_thread_literal", True, 1)):
+            t = time.perf_counter()
+            O.prefilter_mip(pyr, W, spec_size, 2, faces=(0, 1), rows=(0, rows1), literal=literal)
+            dt = time.perf_counter() - t
+            tx = rows1 * size2
+            extra_rates[key] = {"msamples_per_s": tx * 8192 / dt / 1e6, "mc_texels_per_s": tx / dt, "cores": 1,
+                                "sample": f"mip2: {tx} texels x 8192 samples in {dt:.2f} s"}
+    finally:
+        O.set_threads(threads)
     return {
-        "value": total_units / est_time / 1e6, "unit": "Mtexels/s", "cores": threads, "kind": "port",
+        "value": total_units / est_time / 1e6, "unit": "Mtexels/s", "cores": threads, "kind": "port", **extra_rates,
         "sample": f"oracle/pbr_oracle.c (OpenMP, {threads} threads): {n_cp} copy texels + {n_mc} Monte-Carlo texels x 8192 samples "
                   f"({', '.join(sample_desc[:6])}) in {t_mc + t_cp:.1f} s, extrapolated to the whole job "
                   f"({rate_mc * 8192 / 1e6:.1f} Msamples/s, est. {est_time:.0f} s per job)",
@@ -343,28 +358,33 @@ def main():
 
     # HBM traffic per launch from the committed rocprofv3 PMC summary of this same command (profiles/, separate
     # --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction, WRITE_SIZE exact)
-    pmc = {}
+    pmc, pmc_file = {}, f"profiles/r02_{args.workload}_pmc.json"
     try:
-        with open(os.path.join(ROOT, "profiles", f"r01_{args.workload}_pmc.json")) as f:
+        with open(os.path.join(ROOT, pmc_file)) as f:
             pmc = json.load(f).get("kernels", {})
     except Exception:
         pass
+    traffic_keys = {}                                   # which entry of the profile file each traffic figure came from (staleness is visible)
 
-    def traffic_for(kernel_prefix, grid_threads):
+    def traffic_for(kernel_prefix, grid_threads, who=None):
         for name, e in pmc.items():
             if name.startswith(kernel_prefix) and name.endswith(f"grid={grid_threads}"):
                 if "fetch_bytes_corrected_max" in e and "write_bytes_max" in e:
+                    if who:
+                        traffic_keys[who] = f"{pmc_file}: {name}"
                     return e["fetch_bytes_corrected_max"] + e["write_bytes_max"]
+        if who:
+            traffic_keys[who] = f"{pmc_file}: no entry for '{kernel_prefix}' grid={grid_threads} (launch shape changed since the profile was taken)"
         return None
 
     for ent in kernels:
         nm = ent["kernel"]
         if nm.startswith("K4b.prefilter_mc.mip") and world == 1:
             size = max(1, spec_size >> int(nm.rsplit("mip", 1)[1]))
-            if size >= 512:
-                ent["traffic"] = traffic_for("void k_mc_filter<4, 4, true>", 6 * size * size * 4)      # 4 sample slices per texel
+            if size >= 512:            # region kernel: 1024 threads per 16x16 tile (4 sample slices per texel)
+                ent["traffic"] = traffic_for("void k_mc_region<", 6 * size * size * 4, who=nm)
         elif nm.startswith("K4a.") and world == 1:
-            ent["traffic"] = traffic_for("k_prefilter_copy", 256 * 64 * 256)
+            ent["traffic"] = traffic_for("k_prefilter_copy", 6 * spec_size * spec_size, who=nm)
         elif nm == "K2.mip_chain" and world == 1:
             ent["traffic"] = None
 
@@ -373,15 +393,16 @@ def main():
         dom = next((k for k in kernels if "frac" in k), None)
         if dom is not None:
             if dom["bound"] == "valu":
-                roofline = {"kernel": dom["kernel"], "bound": "mfma", "pipe": "fp32 VALU", "achieved": dom["achieved_tflops"],
+                roofline = {"kernel": dom["kernel"], "bound": "valu", "pipe": "fp32 VALU", "achieved": dom["achieved_tflops"],
                             "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": dom.get("traffic"),
-                            "note": "compute-bound Monte-Carlo kernel (SURVEY S9): priced against the dense fp32 peak (157.3 TFLOP/s, "
-                                    "identical for the vector pipe it runs on and for fp32 MFMA); 65 algorithmic flop per non-zero-weight "
-                                    "sample; per-texel bilinear gathers, not a contraction, so no MFMA is used. Measured limiter: vector-memory "
-                                    "instruction issue (3 loads/sample at ~16 clk each), VALU floor ~0.8x of that. HBM-shaped kernels: roofline_hbm"}
+                            "traffic_source": traffic_keys.get(dom["kernel"]),
+                            "note": "compute-bound Monte-Carlo kernel (SURVEY S9): priced against the dense fp32 vector peak (157.3 TFLOP/s at "
+                                    "2.4 GHz); 65 algorithmic flop per non-zero-weight sample (SURVEY 8d) x 6 x size^2 x samples per launch. "
+                                    "Taps come from LDS-staged regions of the source level (k_mc_region); measured limiter: VALU issue "
+                                    "(~39 instructions per sample and lane at ~3 clk each). HBM-shaped kernels: roofline_hbm"}
             else:
                 roofline = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["achieved_gbs"], "peak": PEAK_HBM_GBS,
-                            "unit": "GB/s", "frac": dom["frac"], "traffic": dom.get("traffic")}
+                            "unit": "GB/s", "frac": dom["frac"], "traffic": dom.get("traffic"), "traffic_source": traffic_keys.get(dom["kernel"])}
     roofline_hbm = [{"kernel": k["kernel"], "bound": "hbm", "achieved": k["achieved_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": k["frac"], "avg_ms": k["avg_ms"]} for k in kernels if k.get("bound") == "hbm"]
 

@@ -163,7 +163,9 @@ def test_partition_covers_every_texel_once_and_balances(L):
                 cover[key][f0:f1, r0:r1] += 1
         for k, c in cover.items():
             assert np.all(c == 1), (spec, world, k)
-        assert max(loads) <= 1.08 * (sum(loads) / world), (spec, world, loads)     # cost balance
+        # the partition balances measured TIME (per-level and per-face weights of up to 1.6x around the plain sample count and a
+        # copy level worth ~6 evaluations per texel), so the plain counts agree only roughly
+        assert max(loads) <= 1.3 * (sum(loads) / world), (spec, world, loads)
         # rank < 0 lists everything; partition is deterministic
         assert len(units_of(spec, 1, irr, 2048, world, -1)) == sum(len(units_of(spec, 1, irr, 2048, world, r)) for r in range(world))
         assert units_of(spec, 1, irr, 2048, world, 0) == units_of(spec, 1, irr, 2048, world, 0)
@@ -175,7 +177,7 @@ def test_partition_covers_every_texel_once_and_balances(L):
         assert len(us) <= 10
         assert all(r == 0 for u in us if u[0] == 0 and u[1] == 0) and (r != 0 or any(u[0] == 0 and u[1] == 0 for u in us))
         sent.append(sum((u[3] - u[2]) * (u[5] - u[4]) * (128 if u[0] == 1 else 4096 >> u[1]) * 16 for u in us if not (u[0] == 0 and u[1] == 0)))
-    assert max(sent[1:]) <= 1.15 * min(sent[1:]) and sent[0] > 2 * max(sent[1:])
+    assert max(sent[1:]) <= 1.25 * min(sent[1:]) and sent[0] > 2 * max(sent[1:])
     # reference stop rule: `if (size < 16) break;` (render.cpp:566)
     assert {u[1] for u in units_of(256, 16, 0, 256, 1, 0)} == {0, 1, 2, 3, 4}
 
@@ -204,7 +206,7 @@ def test_partition_property_sweep(L):
                             cover[key][x.face0:x.face1, x.row0:x.row1] += 1
                     assert all(np.all(c == 1) for c in cover.values()), (spec, irr, min_size, world)
                     if spec >= 512 and world <= 8:
-                        assert max(loads) <= 1.1 * sum(loads) / world, (spec, irr, min_size, world)
+                        assert max(loads) <= 1.3 * sum(loads) / world, (spec, irr, min_size, world)    # plain counts; the balance is in measured time
 
 
 GLOO_WORKER = r"""

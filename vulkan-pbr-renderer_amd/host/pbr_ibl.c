@@ -186,30 +186,31 @@ static double samples_per_texel(uint32_t mip) {
     return 8192.0;
 }
 
-/* Measured time per sample-evaluation relative to mip 2 (one MI355X, C4, shares of an 8-way split run through
- * tools/rank_time.py): the MC kernel is a little faster where most weights are large (mip 1); the irradiance pass
- * reads a tiny level.  The copy mip moves 16 B per texel at ~3.4 TB/s, i.e. as long as ~3.8 sample-evaluations per texel.
+/* Measured time per sample-evaluation relative to mip 2 (one MI355X, C4, round 2 kernels: the region kernel serves mips 1-3,
+ * the level-in-LDS kernel mips >= 4; bench.py per-level times divided by 6 * size^2 * non-zero samples): mip 1 runs quarter-face
+ * regions (more passes per tile), mip 3 has 33-cell faces (more samples on two faces), the small levels are launch / tail
+ * limited.  The copy mip writes 16 B per texel at ~3.3 TB/s, i.e. as long as ~5.8 sample-evaluations per texel.
  * Used for balancing only; unit.cost stays the plain count. */
 static double time_weight(const PBR_WorkUnit* u) {
     if (u->kind == PBR_Unit_Irradiance) return 1.24;
     switch (u->mip) {
-    case 0: return 3.8;
-    case 1: return 0.96;
+    case 0: return 5.8;
+    case 1: return 1.24;
     case 2: return 1.0;
-    case 3: return 1.0;
-    case 4: return 1.1;
-    case 5: return 1.1;
-    default: return 1.1;
+    case 3: return 1.18;
+    case 4: return 1.5;
+    case 5: return 1.34;
+    default: return 1.34;
     }
 }
 
 /* Faces 0 and 1 (+-X) contain the pole of the tangent frame (`some_vector`): neighbouring texels there take their samples at
- * different azimuths, the footprints of a wave overlap less, and the same number of sample evaluations takes longer.  Run
- * alone, single-face dispatches differ by +5 %, +8 %, +25 %, +14 %, +5 % for mips 1-5 (tools/face_time.py, C4); next to
- * other dispatches about half of that remains, which is what balances the shares of a 4- and 8-way split
- * (tools/rank_time.py: 17.4-18.05 ms at 8 ranks, 34.4-35.2 ms at 4). */
+ * different azimuths, so the lanes of a wave spread one sample over several regions of the source level and the tile's region
+ * flags are wider.  Run alone, single-face dispatches of the region kernel take 1.27x, 1.30x, 2.0x as long there for mips 1-3
+ * (tools/face_time.py, C4); next to other dispatches roughly two thirds of the excess remains, which is what balances the shares
+ * of a 4- and 8-way split (tools/rank_time.py). */
 static double face_weight(const PBR_WorkUnit* u, uint32_t face) {
-    static const double pole[6] = {1.0, 1.03, 1.04, 1.12, 1.1, 1.05};
+    static const double pole[6] = {1.0, 1.10, 1.12, 1.3, 1.1, 1.05};
     if (u->kind != PBR_Unit_Prefilter || face > 1 || u->mip > 5) return 1.0;
     return pole[u->mip];
 }
