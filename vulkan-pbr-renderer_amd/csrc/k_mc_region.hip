@@ -33,8 +33,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) v4f* ctab_t;
 typedef const __attribute__((address_space(3))) v4f* lds_v4f_p;
 
-#define REG_S 4                 // sample-table slices per workgroup (waves 4s..4s+3 own slice s)
-#define REG_TX 256              // output texels per workgroup (16 x 16)
+// A 1024-thread workgroup owns a TILE x TILE block of output texels and 1024 / TILE^2 slices of the sample table:
+//   TILE 16: 256 texels x 4 slices (waves 4s .. 4s+3 own slice s);   TILE 8: 64 texels x 16 slices (one wave per slice).
+// The smaller tile halves the frame spread delta the region flags are built from (fewer samples flagged for two regions) and
+// pays four times the binning / staging per texel: it wins where regions are small next to that spread (n_src <= 32).
+#define REG_MAX_S 16
 
 struct RegArgs {
     McArgs a;
@@ -42,7 +45,7 @@ struct RegArgs {
     int RC;                     // tap positions (cells) per region edge; the last region of a row may hold fewer
     int NR;                     // 6 * G * G
     int NW;                     // mask words per region = ceil(n_tab / 32)
-    int expect[REG_S];          // samples per slice
+    int expect[REG_MAX_S];      // samples per slice
     unsigned long long* stats;  // optional: [0] += healed wave-slices, [1] += all wave-slices
 };
 
@@ -117,7 +120,7 @@ __device__ __forceinline__ void region_sample(const v4f e, unsigned lds_base, f3
 
 // One pass over the flagged samples of this wave's slice for the staged region.  Samples are taken two at a time so that the
 // second table entry's scalar load is in flight while the first sample computes.
-template <int RS, bool SUB, int CLS>
+template <int RS, bool SUB, int CLS, int REG_S>
 __device__ __forceinline__ void region_pass(unsigned lds_base, const unsigned* __restrict__ mwords, int NW, int s,
                                             ctab_t tab, f3 Pb, f3 Pt, f3 Pr, float half_n, float off,
                                             float ulo, float uhi, float vlo, float vhi,
@@ -141,8 +144,9 @@ __device__ __forceinline__ void region_pass(unsigned lds_base, const unsigned* _
     }
 }
 
-template <int RS, bool SUB>
+template <int RS, bool SUB, int TILE>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mc_region(const RegArgs q) {
+    constexpr int REG_TX = TILE * TILE, REG_S = 1024 / REG_TX;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
     float4* region = (float4*)smem_r;
     const unsigned lds_base = (unsigned)(unsigned long long)smem_r;      // LDS byte offset of the staged region (low half of the flat address)
@@ -151,15 +155,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     unsigned* dmax = any + q.NR;
     const McArgs& p = q.a;
     const int tid = threadIdx.x;
-    const int s = __builtin_amdgcn_readfirstlane(tid >> 8);
-    const int t = tid & 255;
+    const int s = __builtin_amdgcn_readfirstlane(tid / REG_TX);
+    const int t = tid % REG_TX;
 
     unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
     const int face = p.face0 + (int)(tile / (unsigned)p.tiles_per_face);
     const int tf = (int)(tile % (unsigned)p.tiles_per_face);
     const int ty = tf / p.tiles_x, tx = tf % p.tiles_x;
-    const int x = tx * 16 + (t & 15);
-    const int y = p.y0 + ty * 16 + (t >> 4);
+    // a wave covers an 8 x 8 quadrant of the tile (not 16 x 4): the smaller its extent, the fewer samples its lanes spread over
+    // two regions (PBR_MC_WAVE_SHAPE experiment: see DESIGN.md)
+    const int q8 = t >> 6, l8 = t & 63;
+    const int x = tx * TILE + (q8 & 1) * 8 + (l8 & 7);
+    const int y = p.y0 + ty * TILE + (q8 >> 1) * 8 + (l8 >> 3);
     const bool valid = (x < p.size) && (y < p.y0 + p.rows);
     const int xc = min(x, p.size - 1), yc = min(y, p.y0 + p.rows - 1);
 
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const f3 T = tangent_of(R);
     const f3 B = cross3(T, R);
     // tile-centre frame (evaluated redundantly per lane: wave-uniform values)
-    const f3 Rc = face_texel_dir(face, min(tx * 16 + 8, p.size - 1), min(p.y0 + ty * 16 + 8, p.y0 + p.rows - 1), p.size);
+    const f3 Rc = face_texel_dir(face, min(tx * TILE + TILE / 2, p.size - 1), min(p.y0 + ty * TILE + TILE / 2, p.y0 + p.rows - 1), p.size);
     const f3 Tc = tangent_of(Rc);
     const f3 Bc = cross3(Tc, Rc);
 
@@ -201,16 +208,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         for (int f = 0; f < 6; ++f) {
             float sc, tc, ma;
             face_coords(f, Lx, Ly, Lz, sc, tc, ma);
-            // some direction within delta (per component) of L can have face f only if ma + delta >= |sc| - delta (same for tc)
-            if (!(ma + 2.0f * delta >= fabsf(sc)) || !(ma + 2.0f * delta >= fabsf(tc))) continue;
+            // A direction L' with |L' - L|_2 <= delta has ma' - |sc'| <= (ma - |sc|) + sqrt(2) delta: face f needs that >= 0 (same for tc)
+            const float d2 = 1.41421357f * delta;
+            if (!(ma + d2 >= fabsf(sc)) || !(ma + d2 >= fabsf(tc))) continue;
             int lo_u = 0, hi_u = n, lo_v = 0, hi_v = n;
             const float mlo = ma - delta;
             if (mlo > 0.2f) {
-                // |sc'/ma' - sc/ma| <= delta (1 + |sc/ma|) / (ma - delta); + 0.05 texel for the rounding of rcp / fma
+                // g(L) = sc / ma has |grad g| = sqrt(1 + g^2) / ma; along the segment L -> L' (ma >= ma - delta, |g| <= (|sc| + delta) /
+                // (ma - delta)) that is bounded, so |g(L') - g(L)| <= delta sqrt(1 + gmax^2) / (ma - delta); + 0.05 texel for rcp / fma rounding
                 const float rm = 1.0f / ma, rl = 1.0f / mlo;
                 const float ru = sc * rm, rv = tc * rm;
-                const float mu = delta * (1.0f + fabsf(ru)) * rl * half_n + 0.05f;
-                const float mv = delta * (1.0f + fabsf(rv)) * rl * half_n + 0.05f;
+                const float gu = (fabsf(sc) + delta) * rl, gv = (fabsf(tc) + delta) * rl;
+                const float mu = delta * sqrtf(fmaf(gu, gu, 1.0f)) * rl * half_n * 1.0001f + 0.05f;
+                const float mv = delta * sqrtf(fmaf(gv, gv, 1.0f)) * rl * half_n * 1.0001f + 0.05f;
                 const float uc = fmaf(ru, half_n, off), vc = fmaf(rv, half_n, off);
                 const float ul = floorf(uc - mu), uh = floorf(uc + mu), vl = floorf(vc - mv), vh = floorf(vc + mv);
                 if (uh < 0.0f || ul > nf || vh < 0.0f || vl > nf) continue;      // cannot be on this face at all
@@ -251,16 +261,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         const unsigned* mw = masks + r * NW;
         const unsigned pass_base = lds_base - (unsigned)(oy * RS + ox) * 16u;      // taps are addressed with face coordinates
         switch (f >> 1) {
-        case 0: region_pass<RS, SUB, 0>(pass_base, mw, NW, s, tab, Pb, Pt, Pr, half_n, off, (float)ox, (float)(ox + rcx), (float)oy, (float)(oy + rcy), ar, ag, ab, cnt); break;
-        case 1: region_pass<RS, SUB, 1>(pass_base, mw, NW, s, tab, Pb, Pt, Pr, half_n, off, (float)ox, (float)(ox + rcx), (float)oy, (float)(oy + rcy), ar, ag, ab, cnt); break;
-        default: region_pass<RS, SUB, 2>(pass_base, mw, NW, s, tab, Pb, Pt, Pr, half_n, off, (float)ox, (float)(ox + rcx), (float)oy, (float)(oy + rcy), ar, ag, ab, cnt); break;
+        case 0: region_pass<RS, SUB, 0, REG_S>(pass_base, mw, NW, s, tab, Pb, Pt, Pr, half_n, off, (float)ox, (float)(ox + rcx), (float)oy, (float)(oy + rcy), ar, ag, ab, cnt); break;
+        case 1: region_pass<RS, SUB, 1, REG_S>(pass_base, mw, NW, s, tab, Pb, Pt, Pr, half_n, off, (float)ox, (float)(ox + rcx), (float)oy, (float)(oy + rcy), ar, ag, ab, cnt); break;
+        default: region_pass<RS, SUB, 2, REG_S>(pass_base, mw, NW, s, tab, Pb, Pt, Pr, half_n, off, (float)ox, (float)(ox + rcx), (float)oy, (float)(oy + rcy), ar, ag, ab, cnt); break;
         }
     }
 
     // ---- 3. completeness check; a wave that missed a sample recomputes its slice with direct loads ----
     // cnt is a wave total (scalar): no (texel, sample) pair can be taken twice -- the in-region tests partition the tap positions
     // exactly -- so the total is right exactly when no lane missed a sample
-    const unsigned expect = 64u * (unsigned)(s == 0 ? q.expect[0] : (s == 1 ? q.expect[1] : (s == 2 ? q.expect[2] : q.expect[3])));
+    const unsigned expect = 64u * (unsigned)q.expect[s];
     const bool healed = cnt != expect;
     if (healed) {
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)p.src_bytes, 0x00020000);
@@ -315,11 +325,11 @@ extern "C" int pbrk_mc_region_stats(unsigned long long* out2, int reset) {
     return PBRK_OK;
 }
 
-template <int RS, bool SUB>
+template <int RS, bool SUB, int TILE>
 static void launch_region_t(const RegArgs& q, unsigned grid, size_t lds, hipStream_t st) {
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_mc_region<RS, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-    hipLaunchKernelGGL((k_mc_region<RS, SUB>), dim3(grid), dim3(1024), lds, st, q);
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_mc_region<RS, SUB, TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL((k_mc_region<RS, SUB, TILE>), dim3(grid), dim3(1024), lds, st, q);
 }
 
 bool launch_mc_region(McArgs a, int nfaces, hipStream_t st) {
@@ -337,21 +347,44 @@ bool launch_mc_region(McArgs a, int nfaces, hipStream_t st) {
     q.NR = 6 * q.G * q.G;
     q.NW = (a.n_tab + 31) / 32;
     size_t lds = (size_t)RS * RS * 16 + ((size_t)q.NR * q.NW + q.NR + 4) * 4;
-    if (lds < (size_t)REG_S * REG_TX * 3 * 4) lds = (size_t)REG_S * REG_TX * 3 * 4;
+    if (lds < (size_t)1024 * 3 * 4) lds = (size_t)1024 * 3 * 4;      // the slices' partial sums (REG_S * REG_TX = 1024 texel-slices)
     if (lds > 80 * 1024) return false;                             // two workgroups per CU or not at all
-    for (int s = 0; s < REG_S; ++s) q.expect[s] = 0;
-    for (int w = 0; w < q.NW; ++w) { int c = a.n_tab - w * 32; q.expect[w % REG_S] += c > 32 ? 32 : c; }
+    static int tile_override = -1;
+    if (tile_override < 0) { const char* e = getenv("PBR_MC_TILE"); tile_override = e ? atoi(e) : 0; }
     if (stats_on < 0) {
         const char* e = getenv("PBR_MC_STATS"); stats_on = e ? atoi(e) : 0;
         if (stats_on) { if (hipMalloc(&g_reg_stats, 16) != hipSuccess) g_reg_stats = nullptr; else (void)hipMemset(g_reg_stats, 0, 16); }
     }
     q.stats = g_reg_stats;
-    q.a.tiles_x = (a.size + 15) / 16;
-    int tiles_y = (a.rows + 15) / 16;
-    q.a.tiles_per_face = q.a.tiles_x * tiles_y;
-    unsigned grid = (unsigned)(q.a.tiles_per_face * nfaces);
-    if (RS == 34) launch_region_t<34, false>(q, grid, lds, st);
-    else if (q.G == 1) launch_region_t<66, false>(q, grid, lds, st);
-    else launch_region_t<66, true>(q, grid, lds, st);
+    // Tile size: 16 x 16 everywhere.  8 x 8 tiles (PBR_MC_TILE=8, an experiment kept for the record) halve the frame spread the
+    // region flags are built from but pay four times the per-tile work (binning, staging, prologue): C4 mip 2 44.0 -> 53.5 ms,
+    // mip 3 12.0 -> 13.6 ms, mip 1 37.0 -> 54.5 ms; even restricted to the faces that hold the pole of the tangent frame (+-X: a
+    // single-face dispatch of mip 3 runs 4.1 -> 3.0 ms) the second launch costs more than it saves (12.0 -> 12.8 ms per level).
+    const bool split = false;
+    for (int part = 0; part < 2; ++part) {
+        int f0 = a.face0, f1 = a.face0 + nfaces;
+        if (split) { if (part == 0) f1 = f1 < 2 ? f1 : 2; else f0 = f0 > 2 ? f0 : 2; }
+        else if (part == 1) break;
+        if (f0 >= f1) continue;
+        int tile = (split && part == 0) ? 8 : 16;
+        if (tile_override == 8 || tile_override == 16) tile = tile_override;
+        const int nslices = 1024 / (tile * tile);
+        for (int s = 0; s < REG_MAX_S; ++s) q.expect[s] = 0;
+        for (int w = 0; w < q.NW; ++w) { int c = a.n_tab - w * 32; q.expect[w % nslices] += c > 32 ? 32 : c; }
+        q.a.face0 = f0;
+        q.a.tiles_x = (a.size + tile - 1) / tile;
+        int tiles_y = (a.rows + tile - 1) / tile;
+        q.a.tiles_per_face = q.a.tiles_x * tiles_y;
+        unsigned grid = (unsigned)(q.a.tiles_per_face * (f1 - f0));
+        if (tile == 8) {
+            if (RS == 34) launch_region_t<34, false, 8>(q, grid, lds, st);
+            else if (q.G == 1) launch_region_t<66, false, 8>(q, grid, lds, st);
+            else launch_region_t<66, true, 8>(q, grid, lds, st);
+        } else {
+            if (RS == 34) launch_region_t<34, false, 16>(q, grid, lds, st);
+            else if (q.G == 1) launch_region_t<66, false, 16>(q, grid, lds, st);
+            else launch_region_t<66, true, 16>(q, grid, lds, st);
+        }
+    }
     return true;
 }
