@@ -46,6 +46,7 @@ struct RegArgs {
     int NR;                     // 6 * G * G
     int NW;                     // mask words per region = ceil(n_tab / 32)
     int expect[REG_MAX_S];      // samples per slice
+    int tile_y0;                // MFMA variant: first tile row (multiple of 16) covering a.y0
     unsigned long long* stats;  // optional: [0] += healed wave-slices, [1] += all wave-slices
 };
 
@@ -144,6 +145,67 @@ __device__ __forceinline__ void region_pass(unsigned lds_base, const unsigned* _
     }
 }
 
+// Binning (once per tile): which regions of the source level can the samples reach from ANY texel of the tile?  Every sample
+// direction is pushed through the tile-centre frame; a rigorous bound on how far a texel's own frame can move it yields the
+// regions; one bit per (region, sample) in `masks`, any[r] != 0 when region r has a bit.  Leaves with a barrier pending: callers
+// synchronise before reading the masks.
+__device__ __forceinline__ void region_bin(unsigned* masks, unsigned* any, unsigned* dmax, int NR, int NW, int G, int RC, int n,
+                                           f3 R, f3 T, f3 B, f3 Rc, f3 Tc, f3 Bc, ctab_t tab, int n_tab, int tid) {
+    const float nf = (float)n;
+    const float half_n = 0.5f * nf;
+    const float off = 0.5f * nf + 0.5f;
+    for (int k = tid; k < NR * NW + NR + 1; k += 1024) masks[k] = 0u;
+    __syncthreads();
+    {
+        f3 dR = sub3(R, Rc), dT = sub3(T, Tc), dB = sub3(B, Bc);
+        float d2 = dot3(dR, dR) + dot3(dT, dT) + dot3(dB, dB);
+        atomicMax(dmax, __float_as_uint(sqrtf(d2)));                 // non-negative floats order like their bit patterns
+    }
+    __syncthreads();
+    // |L_texel - L_centre| <= |M_texel - M_centre|_2 for a unit local direction.  Both frames are orthonormal, so M_t - M_c =
+    // (Rot - I) M_c with singular values {0, 2 sin(theta/2), 2 sin(theta/2)}: the spectral norm is the Frobenius norm / sqrt(2).
+    // Inflated for the frames' own rounding (1e-7) and that of both evaluations.
+    const float delta = __uint_as_float(*dmax) * 0.70710678f * 1.001f + 4e-6f;
+    for (int i = tid; i < n_tab; i += 1024) {
+        const v4f e = tab[i];
+        const float Lx = fmaf(e.x, Bc.x, fmaf(e.y, Tc.x, e.z * Rc.x));
+        const float Ly = fmaf(e.x, Bc.y, fmaf(e.y, Tc.y, e.z * Rc.y));
+        const float Lz = fmaf(e.x, Bc.z, fmaf(e.y, Tc.z, e.z * Rc.z));
+        const unsigned bit = 1u << (i & 31);
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            float sc, tc, ma;
+            face_coords(f, Lx, Ly, Lz, sc, tc, ma);
+            // A direction L' with |L' - L|_2 <= delta has ma' - |sc'| <= (ma - |sc|) + sqrt(2) delta: face f needs that >= 0 (same for tc)
+            const float d2 = 1.41421357f * delta;
+            if (!(ma + d2 >= fabsf(sc)) || !(ma + d2 >= fabsf(tc))) continue;
+            int lo_u = 0, hi_u = n, lo_v = 0, hi_v = n;
+            const float mlo = ma - delta;
+            if (mlo > 0.2f) {
+                // g(L) = sc / ma has |grad g| = sqrt(1 + g^2) / ma; along the segment L -> L' (ma >= ma - delta, |g| <= (|sc| + delta) /
+                // (ma - delta)) that is bounded, so |g(L') - g(L)| <= delta sqrt(1 + gmax^2) / (ma - delta); + 0.05 texel for rcp / fma rounding
+                const float rm = 1.0f / ma, rl = 1.0f / mlo;
+                const float ru = sc * rm, rv = tc * rm;
+                const float gu = (fabsf(sc) + delta) * rl, gv = (fabsf(tc) + delta) * rl;
+                const float mu = delta * sqrtf(fmaf(gu, gu, 1.0f)) * rl * half_n * 1.0001f + 0.05f;
+                const float mv = delta * sqrtf(fmaf(gv, gv, 1.0f)) * rl * half_n * 1.0001f + 0.05f;
+                const float uc = fmaf(ru, half_n, off), vc = fmaf(rv, half_n, off);
+                const float ul = floorf(uc - mu), uh = floorf(uc + mu), vl = floorf(vc - mv), vh = floorf(vc + mv);
+                if (uh < 0.0f || ul > nf || vh < 0.0f || vl > nf) continue;      // cannot be on this face at all
+                lo_u = (int)fmaxf(ul, 0.0f); hi_u = (int)fminf(uh, nf);
+                lo_v = (int)fmaxf(vl, 0.0f); hi_v = (int)fminf(vh, nf);
+            }
+            const int gx0 = lo_u / RC, gx1 = hi_u / RC, gy0 = lo_v / RC, gy1 = hi_v / RC;
+            for (int gy = gy0; gy <= gy1; ++gy)
+                for (int gx = gx0; gx <= gx1; ++gx) {
+                    const int r = (f * G + gy) * G + gx;
+                    atomicOr(&masks[r * NW + (i >> 5)], bit);
+                    any[r] = 1u;
+                }
+        }
+    }
+}
+
 template <int RS, bool SUB, int TILE>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mc_region(const RegArgs q) {
     constexpr int REG_TX = TILE * TILE, REG_S = 1024 / REG_TX;
@@ -186,56 +248,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const int NW = q.NW, NR = q.NR, G = q.G, RC = q.RC;
 
     // ---- 1. binning ----
-    for (int k = tid; k < NR * NW + NR + 1; k += 1024) masks[k] = 0u;
-    __syncthreads();
-    {
-        f3 dR = sub3(R, Rc), dT = sub3(T, Tc), dB = sub3(B, Bc);
-        float d2 = dot3(dR, dR) + dot3(dT, dT) + dot3(dB, dB);
-        atomicMax(dmax, __float_as_uint(sqrtf(d2)));                 // non-negative floats order like their bit patterns
-    }
-    __syncthreads();
-    // |L_texel - L_centre| <= |M_texel - M_centre|_2 for a unit local direction.  Both frames are orthonormal, so M_t - M_c =
-    // (Rot - I) M_c with singular values {0, 2 sin(theta/2), 2 sin(theta/2)}: the spectral norm is the Frobenius norm / sqrt(2).
-    // Inflated for the frames' own rounding (1e-7) and that of both evaluations.
-    const float delta = __uint_as_float(*dmax) * 0.70710678f * 1.001f + 4e-6f;
-    for (int i = tid; i < p.n_tab; i += 1024) {
-        const v4f e = tab[i];
-        const float Lx = fmaf(e.x, Bc.x, fmaf(e.y, Tc.x, e.z * Rc.x));
-        const float Ly = fmaf(e.x, Bc.y, fmaf(e.y, Tc.y, e.z * Rc.y));
-        const float Lz = fmaf(e.x, Bc.z, fmaf(e.y, Tc.z, e.z * Rc.z));
-        const unsigned bit = 1u << (i & 31);
-#pragma unroll
-        for (int f = 0; f < 6; ++f) {
-            float sc, tc, ma;
-            face_coords(f, Lx, Ly, Lz, sc, tc, ma);
-            // A direction L' with |L' - L|_2 <= delta has ma' - |sc'| <= (ma - |sc|) + sqrt(2) delta: face f needs that >= 0 (same for tc)
-            const float d2 = 1.41421357f * delta;
-            if (!(ma + d2 >= fabsf(sc)) || !(ma + d2 >= fabsf(tc))) continue;
-            int lo_u = 0, hi_u = n, lo_v = 0, hi_v = n;
-            const float mlo = ma - delta;
-            if (mlo > 0.2f) {
-                // g(L) = sc / ma has |grad g| = sqrt(1 + g^2) / ma; along the segment L -> L' (ma >= ma - delta, |g| <= (|sc| + delta) /
-                // (ma - delta)) that is bounded, so |g(L') - g(L)| <= delta sqrt(1 + gmax^2) / (ma - delta); + 0.05 texel for rcp / fma rounding
-                const float rm = 1.0f / ma, rl = 1.0f / mlo;
-                const float ru = sc * rm, rv = tc * rm;
-                const float gu = (fabsf(sc) + delta) * rl, gv = (fabsf(tc) + delta) * rl;
-                const float mu = delta * sqrtf(fmaf(gu, gu, 1.0f)) * rl * half_n * 1.0001f + 0.05f;
-                const float mv = delta * sqrtf(fmaf(gv, gv, 1.0f)) * rl * half_n * 1.0001f + 0.05f;
-                const float uc = fmaf(ru, half_n, off), vc = fmaf(rv, half_n, off);
-                const float ul = floorf(uc - mu), uh = floorf(uc + mu), vl = floorf(vc - mv), vh = floorf(vc + mv);
-                if (uh < 0.0f || ul > nf || vh < 0.0f || vl > nf) continue;      // cannot be on this face at all
-                lo_u = (int)fmaxf(ul, 0.0f); hi_u = (int)fminf(uh, nf);
-                lo_v = (int)fmaxf(vl, 0.0f); hi_v = (int)fminf(vh, nf);
-            }
-            const int gx0 = lo_u / RC, gx1 = hi_u / RC, gy0 = lo_v / RC, gy1 = hi_v / RC;
-            for (int gy = gy0; gy <= gy1; ++gy)
-                for (int gx = gx0; gx <= gx1; ++gx) {
-                    const int r = (f * G + gy) * G + gx;
-                    atomicOr(&masks[r * NW + (i >> 5)], bit);
-                    any[r] = 1u;
-                }
-        }
-    }
+    region_bin(masks, any, dmax, NR, NW, G, RC, n, R, T, B, Rc, Tc, Bc, tab, p.n_tab, tid);
 
     // ---- 2. region passes ----
     float ar = 0.0f, ag = 0.0f, ab = 0.0f;
@@ -316,6 +329,236 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     }
 }
 
+// ==========================================================================================
+// MFMA variant: the frame transform on the matrix pipe.
+//
+// L = e.x B + e.y T + e.z R is a K = 3 contraction: (samples x 3) . (3 x texels) per cube-coordinate.  v_mfma_f32_16x16x4_f32
+// (exact fp32, the k-ordered fmaf chain of the scalar code bit for bit) computes it for 16 samples x 16 texels at a time on the
+// matrix pipe, which runs beside the VALU; K = 4's spare slot carries the sample weight (B row (0,0,0,1)).  That fixes the lane
+// layout: a wave owns 16 texels (a 4 x 4 block of the tile; lane & 15) and its four lane groups (lane >> 4) take the sample rows
+// 4g .. 4g+3 of every 16-sample block; the 16 waves of a workgroup cover the 16 x 16 tile and all walk the same sample list.
+//   * the per-(region, sample) flags are compacted once per pass into a list of sample indices in LDS (chunks of LIST_CAP);
+//   * per block: one 2-byte LDS read + one 4-byte table gather per lane (the A operand: lane (row, k) holds component k of
+//     sample `row` in the order (z, y, x, w)), four MFMAs (sc, tc, ma, weight; B operand = the lane's own column of the
+//     permuted frame), then the four samples of the lane run the in-region test / LDS taps / accumulate exactly as above;
+//   * the four groups' sums are folded with a fixed xor-butterfly at the end.
+// 30 VALU instructions per sample and lane instead of 39.  The order of a texel's sum (region, list position, row) depends on
+// the tile's flags, so tiles are anchored at multiples of 16 rows of the LEVEL: a row-sharded dispatch runs the same tiles.
+//
+// MEASURED (MI355X, C4 mip 2): correct (bit-for-bit the same taps and weights, zero recomputed waves), 16.5 % fewer VALU and
+// 30 % fewer SALU instructions per wave (SQ_INSTS_VALU 92.6k -> 77.3k) -- and SLOWER: 48.1 ms against 43.9 ms.  The fp32-input
+// MFMA runs at the fp32 vector rate because it runs ON the vector multipliers: its four 32-cycle issues per block hold the
+// SIMD for as long as the 36 FMAs they replace, plus a 40-cycle dependency and a gather per block.  There is no idle matrix
+// pipe to offload fp32 work to on gfx950.  The variant stays as an opt-in (PBR_MC_MFMA=1) record of that result.
+// ==========================================================================================
+#define LIST_CAP 2048
+typedef const __attribute__((address_space(3))) unsigned short* lds_u16_p;
+
+template <int RS, bool SUB, int CLS>
+__device__ __forceinline__ void mfma_sample(const float sc, const float tc, const float ma, const float wgt, const unsigned long long vmask,
+                                            unsigned lds_base, float half_n, float off, float ulo, float uhi, float vlo, float vhi,
+                                            float& ar, float& ag, float& ab, unsigned& cnt) {
+    bool c1, c2;
+    if (CLS == 0) { c1 = ma > fabsf(sc); c2 = ma > fabsf(tc); }
+    else if (CLS == 1) { c1 = ma >= fabsf(sc); c2 = ma > fabsf(tc); }
+    else { c1 = ma >= fabsf(sc); c2 = ma >= fabsf(tc); }
+    unsigned long long inm = __builtin_amdgcn_ballot_w64(c1) & __builtin_amdgcn_ballot_w64(c2);
+    if (inm == 0) return;                                           // none of the 64 (texel, sample) pairs is on this face
+    bool in = c1 && c2;
+    const float h = __builtin_amdgcn_rcpf(ma) * half_n;
+    const float u = fmaf(sc, h, off), v = fmaf(tc, h, off);
+    const int il = (int)u, jl = (int)v;
+    if (SUB) {
+        const bool c3 = u >= ulo, c4 = u < uhi, c5 = v >= vlo, c6 = v < vhi;
+        inm &= __builtin_amdgcn_ballot_w64(c3) & __builtin_amdgcn_ballot_w64(c4) & __builtin_amdgcn_ballot_w64(c5) & __builtin_amdgcn_ballot_w64(c6);
+        in = in && c3 && c4 && c5 && c6;
+    }
+    cnt += (unsigned)__builtin_popcountll(inm & vmask);             // padding rows of a list's last block do not count
+    if (in) {
+        const float a = __builtin_amdgcn_fractf(u), b = __builtin_amdgcn_fractf(v);
+        unsigned t16, addr;
+        asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(t16) : "v"(il), "s"(lds_base));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(jl), "s"(RS * 16), "v"(t16));
+        lds_v4f_p tp = (lds_v4f_p)(unsigned long long)addr;
+        v4f q00 = tp[0], q10 = tp[1], q01 = tp[RS], q11 = tp[RS + 1];
+        asm("" : "+v"(q00)); asm("" : "+v"(q10)); asm("" : "+v"(q01)); asm("" : "+v"(q11));
+        const float wa = wgt * a;
+        const float w11 = wa * b;
+        const float w10 = wa - w11;
+        const float wt = wgt - wa;
+        const float w01 = wt * b;
+        const float w00 = wt - w01;
+        ar = fmaf(w11, q11.x, fmaf(w01, q01.x, fmaf(w10, q10.x, fmaf(w00, q00.x, ar))));
+        ag = fmaf(w11, q11.y, fmaf(w01, q01.y, fmaf(w10, q10.y, fmaf(w00, q00.y, ag))));
+        ab = fmaf(w11, q11.z, fmaf(w01, q01.z, fmaf(w10, q10.z, fmaf(w00, q00.z, ab))));
+    }
+}
+
+// all blocks of the list chunk [0, count) for this wave's 16 texels
+template <int RS, bool SUB, int CLS>
+__device__ __forceinline__ void mfma_chunk(lds_u16_p list, int count, const float* __restrict__ tabf, int comp, int row, int g,
+                                           float bsc, float btc, float bma, float bw,
+                                           unsigned lds_base, float half_n, float off, float ulo, float uhi, float vlo, float vhi,
+                                           float& ar, float& ag, float& ab, unsigned& cnt) {
+    const v4f zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int pos = 0; pos < count; pos += 16) {
+        const int nvalid = min(16, count - pos);                    // wave-uniform
+        const int idx = (int)list[pos + min(row, nvalid - 1)];
+        float aval = tabf[idx * 4 + comp];
+        unsigned long long vm0 = ~0ull, vm1 = ~0ull, vm2 = ~0ull, vm3 = ~0ull;
+        if (nvalid < 16) {                                          // last block of the list: rows >= nvalid repeat the last sample with weight 0
+            if (g == 3 && row >= nvalid) aval = 0.0f;
+            vm0 = __builtin_amdgcn_ballot_w64(4 * g + 0 < nvalid); vm1 = __builtin_amdgcn_ballot_w64(4 * g + 1 < nvalid);
+            vm2 = __builtin_amdgcn_ballot_w64(4 * g + 2 < nvalid); vm3 = __builtin_amdgcn_ballot_w64(4 * g + 3 < nvalid);
+        }
+        // D[row 4g + i][texel] in element i: (sc, tc, ma) = e.z R' + e.y T' + e.x B' in that order (k = 0, 1, 2), weight through k = 3
+        const v4f dsc = __builtin_amdgcn_mfma_f32_16x16x4f32(aval, bsc, zero, 0, 0, 0);
+        const v4f dtc = __builtin_amdgcn_mfma_f32_16x16x4f32(aval, btc, zero, 0, 0, 0);
+        const v4f dma = __builtin_amdgcn_mfma_f32_16x16x4f32(aval, bma, zero, 0, 0, 0);
+        const v4f dwv = __builtin_amdgcn_mfma_f32_16x16x4f32(aval, bw, zero, 0, 0, 0);
+        mfma_sample<RS, SUB, CLS>(dsc.x, dtc.x, dma.x, dwv.x, vm0, lds_base, half_n, off, ulo, uhi, vlo, vhi, ar, ag, ab, cnt);
+        mfma_sample<RS, SUB, CLS>(dsc.y, dtc.y, dma.y, dwv.y, vm1, lds_base, half_n, off, ulo, uhi, vlo, vhi, ar, ag, ab, cnt);
+        mfma_sample<RS, SUB, CLS>(dsc.z, dtc.z, dma.z, dwv.z, vm2, lds_base, half_n, off, ulo, uhi, vlo, vhi, ar, ag, ab, cnt);
+        mfma_sample<RS, SUB, CLS>(dsc.w, dtc.w, dma.w, dwv.w, vm3, lds_base, half_n, off, ulo, uhi, vlo, vhi, ar, ag, ab, cnt);
+    }
+}
+
+template <int RS, bool SUB>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mc_region_mfma(const RegArgs q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
+    float4* region = (float4*)smem_r;
+    const unsigned lds_base = (unsigned)(unsigned long long)smem_r;
+    unsigned* masks = (unsigned*)(smem_r + RS * RS * 16);
+    unsigned* any = masks + q.NR * q.NW;
+    unsigned* dmax = any + q.NR;
+    unsigned* offs = dmax + 1;                                     // [NW + 1] exclusive prefix of the mask words' bit counts (current region)
+    unsigned short* list = (unsigned short*)(offs + q.NW + 1);     // [LIST_CAP] sample indices of the current chunk
+    const McArgs& p = q.a;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, row = lane & 15, g = lane >> 4;
+
+    unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int face = p.face0 + (int)(tile / (unsigned)p.tiles_per_face);
+    const int tf = (int)(tile % (unsigned)p.tiles_per_face);
+    const int ty = tf / p.tiles_x, tx = tf % p.tiles_x;
+    const int x = tx * 16 + (wave & 3) * 4 + (row & 3);
+    const int y = q.tile_y0 + ty * 16 + (wave >> 2) * 4 + (row >> 2);
+    const bool valid = (x < p.size) && (y >= p.y0) && (y < p.y0 + p.rows);
+    const int xc = min(x, p.size - 1), yc = min(y, p.size - 1);    // clamped to the LEVEL: a tile's frames do not depend on the dispatched rows
+
+    const int n = p.n_src, nb = n + 2;
+    const float nf = (float)n;
+    const float half_n = 0.5f * nf;
+    const float off = 0.5f * nf + 0.5f;
+    ctab_t tab = (ctab_t)(unsigned long long)p.tab;
+    const int NW = q.NW, NR = q.NR, G = q.G, RC = q.RC;
+
+    f3 Fg;                                                          // this lane's column of the frame: group 0 R, 1 T, 2 B, 3 none (weight slot)
+    {
+        const f3 R = face_texel_dir(face, xc, yc, p.size);
+        const f3 T = tangent_of(R);
+        const f3 B = cross3(T, R);
+        const f3 Rc = face_texel_dir(face, min(tx * 16 + 8, p.size - 1), min(q.tile_y0 + ty * 16 + 8, p.size - 1), p.size);
+        const f3 Tc = tangent_of(Rc);
+        const f3 Bc = cross3(Tc, Rc);
+        for (int k = tid; k < NR * NW + NR + 1; k += 1024) masks[k] = 0u;
+        __syncthreads();
+        region_bin(masks, any, dmax, NR, NW, G, RC, n, R, T, B, Rc, Tc, Bc, tab, p.n_tab, tid);
+        Fg = g == 0 ? R : (g == 1 ? T : (g == 2 ? B : mk3(0.0f, 0.0f, 0.0f)));
+    }
+    const float bw = g == 3 ? 1.0f : 0.0f;
+    const int comp = g == 0 ? 2 : (g == 1 ? 1 : (g == 2 ? 0 : 3));    // table component of this lane's k: (z, y, x, w)
+    const float* __restrict__ tabf = (const float*)p.tab;
+
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    unsigned cnt = 0;
+    for (int r = 0; r < NR; ++r) {
+        __syncthreads();                                           // binning done / readers of the previous region and list done
+        if (any[r] == 0u) continue;                                // workgroup-uniform
+        const int f = r / (G * G);
+        const int gy = (r / G) % G, gx = r % G;
+        const int ox = gx * RC, oy = gy * RC;
+        const int rcx = min(RC, n + 1 - ox), rcy = min(RC, n + 1 - oy);
+        const float4* __restrict__ fsrc = p.src + ((size_t)f * nb + oy) * nb + ox;
+        for (int k = tid; k < RS * RS; k += 1024) {
+            const int ry = k / RS, rx = k - ry * RS;
+            if (rx <= rcx && ry <= rcy) region[k] = fsrc[ry * nb + rx];
+        }
+        const unsigned* mw = masks + r * NW;
+        if (wave == 0) {                                           // exclusive prefix of the words' bit counts: 4 words per lane + wave scan
+            unsigned c[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int w = lane * 4 + j; c[j] = w < NW ? (unsigned)__builtin_popcount(mw[w]) : 0u; sum += c[j]; }
+            unsigned incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { unsigned v = (unsigned)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
+            unsigned run = incl - sum;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int w = lane * 4 + j; if (w < NW) offs[w] = run; run += c[j]; }
+            if (lane == 63) offs[NW] = incl;
+        }
+        __syncthreads();
+        const int total = (int)offs[NW];
+        float bsc, btc, bma;
+        face_coords(f, Fg.x, Fg.y, Fg.z, bsc, btc, bma);
+        const unsigned pass_base = lds_base - (unsigned)(oy * RS + ox) * 16u;
+        const float ulo = (float)ox, uhi = (float)(ox + rcx), vlo = (float)oy, vhi = (float)(oy + rcy);
+        for (int c0 = 0; c0 < total; c0 += LIST_CAP) {
+            if (c0 > 0) __syncthreads();                           // readers of the previous chunk are done
+            if (tid < NW) {                                        // thread t writes the set bits of word t that fall into this chunk
+                unsigned m = mw[tid];
+                int pidx = (int)offs[tid] - c0;
+                while (m) {
+                    const int bpos = __builtin_ctz(m);
+                    m &= m - 1u;
+                    if ((unsigned)pidx < (unsigned)LIST_CAP) list[pidx] = (unsigned short)((tid << 5) + bpos);
+                    ++pidx;
+                }
+            }
+            __syncthreads();
+            const int count = min(LIST_CAP, total - c0);
+            lds_u16_p lp = (lds_u16_p)(unsigned long long)(unsigned)(unsigned long long)list;
+            switch (f >> 1) {
+            case 0: mfma_chunk<RS, SUB, 0>(lp, count, tabf, comp, row, g, bsc, btc, bma, bw, pass_base, half_n, off, ulo, uhi, vlo, vhi, ar, ag, ab, cnt); break;
+            case 1: mfma_chunk<RS, SUB, 1>(lp, count, tabf, comp, row, g, bsc, btc, bma, bw, pass_base, half_n, off, ulo, uhi, vlo, vhi, ar, ag, ab, cnt); break;
+            default: mfma_chunk<RS, SUB, 2>(lp, count, tabf, comp, row, g, bsc, btc, bma, bw, pass_base, half_n, off, ulo, uhi, vlo, vhi, ar, ag, ab, cnt); break;
+            }
+        }
+    }
+
+    // completeness: every (texel, sample) pair of this wave exactly once; else the wave recomputes its 16 texels with direct loads
+    const bool healed = cnt != 16u * (unsigned)p.n_tab;
+    if (healed) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)p.src_bytes, 0x00020000);
+        const f3 R = face_texel_dir(face, xc, yc, p.size);
+        const f3 T = tangent_of(R);
+        const f3 B = cross3(T, R);
+        ar = 0.0f; ag = 0.0f; ab = 0.0f;
+        for (int i = g; i < p.n_tab; i += 4) {
+            const float4 e = p.tab[i];
+            f3 L;
+            L.x = fmaf(e.x, B.x, fmaf(e.y, T.x, e.z * R.x));
+            L.y = fmaf(e.x, B.y, fmaf(e.y, T.y, e.z * R.y));
+            L.z = fmaf(e.x, B.z, fmaf(e.y, T.z, e.z * R.z));
+            f3 c = sample_bordered<false>(rs, L, nf, off, nb, nb * 16);
+            ar = fmaf(e.w, c.x, ar); ag = fmaf(e.w, c.y, ag); ab = fmaf(e.w, c.z, ab);
+        }
+    }
+    if (q.stats && lane == 0) {
+        if (healed) atomicAdd(&q.stats[0], 1ull);
+        atomicAdd(&q.stats[1], 1ull);
+    }
+    // fold the four lane groups: (g0 + g1) + (g2 + g3)
+    ar += __shfl_xor(ar, 16); ag += __shfl_xor(ag, 16); ab += __shfl_xor(ab, 16);
+    ar += __shfl_xor(ar, 32); ag += __shfl_xor(ag, 32); ab += __shfl_xor(ab, 32);
+    if (valid && g == 0) {
+        float4 o;
+        o.x = ar / p.divisor; o.y = ag / p.divisor; o.z = ab / p.divisor; o.w = p.alpha;
+        p.out[((size_t)face * p.size + y) * p.size + x] = o;
+    }
+}
+
 static unsigned long long* g_reg_stats = nullptr;      // device counters, enabled by PBR_MC_STATS=1
 
 extern "C" int pbrk_mc_region_stats(unsigned long long* out2, int reset) {
@@ -332,16 +575,24 @@ static void launch_region_t(const RegArgs& q, unsigned grid, size_t lds, hipStre
     hipLaunchKernelGGL((k_mc_region<RS, SUB, TILE>), dim3(grid), dim3(1024), lds, st, q);
 }
 
+template <int RS, bool SUB>
+static void launch_mfma_t(const RegArgs& q, unsigned grid, size_t lds, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_mc_region_mfma<RS, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL((k_mc_region_mfma<RS, SUB>), dim3(grid), dim3(1024), lds, st, q);
+}
+
 bool launch_mc_region(McArgs a, int nfaces, hipStream_t st) {
     static int mode = -1, stats_on = -1;
     if (mode < 0) { const char* e = getenv("PBR_MC_REGION"); mode = e ? atoi(e) : 1; }
     if (!mode) return false;
     // shape conditions (level only): source too big for LDS as a whole, enough 16x16 tiles to fill the chip twice over
-    if (a.n_src < 24 || a.size < 256 || a.n_tab < 1 || a.n_tab > 8192) return false;
+    if (a.n_src < 16 || a.size < 256 || a.n_tab < 1 || a.n_tab > 8192) return false;
     RegArgs q;
     q.a = a;
     int RS;
-    if (a.n_src <= 32) { RS = 34; q.G = 1; q.RC = a.n_src + 1; }
+    if (a.n_src <= 16) { RS = 18; q.G = 1; q.RC = a.n_src + 1; }
+    else if (a.n_src <= 32) { RS = 34; q.G = 1; q.RC = a.n_src + 1; }
     else if (a.n_src <= 64) { RS = 66; q.G = 1; q.RC = a.n_src + 1; }
     else { RS = 66; q.RC = 65; q.G = (a.n_src + 1 + 64) / 65; }
     q.NR = 6 * q.G * q.G;
@@ -360,6 +611,23 @@ bool launch_mc_region(McArgs a, int nfaces, hipStream_t st) {
     // region flags are built from but pay four times the per-tile work (binning, staging, prologue): C4 mip 2 44.0 -> 53.5 ms,
     // mip 3 12.0 -> 13.6 ms, mip 1 37.0 -> 54.5 ms; even restricted to the faces that hold the pole of the tangent frame (+-X: a
     // single-face dispatch of mip 3 runs 4.1 -> 3.0 ms) the second launch costs more than it saves (12.0 -> 12.8 ms per level).
+    static int mfma_mode = -1;
+    if (mfma_mode < 0) { const char* e = getenv("PBR_MC_MFMA"); mfma_mode = e ? atoi(e) : 0; }      // opt-in: measured slower (see above)
+    if (mfma_mode && q.NW <= 256) {
+        size_t lds_m = (size_t)RS * RS * 16 + ((size_t)q.NR * q.NW + q.NR + 1 + q.NW + 1) * 4 + (size_t)LIST_CAP * 2;
+        lds_m = (lds_m + 15) & ~(size_t)15;
+        if (lds_m <= 80 * 1024) {
+            q.tile_y0 = (a.y0 / 16) * 16;
+            q.a.tiles_x = (a.size + 15) / 16;
+            q.a.tiles_per_face = q.a.tiles_x * ((a.y0 + a.rows - q.tile_y0 + 15) / 16);
+            unsigned grid = (unsigned)(q.a.tiles_per_face * nfaces);
+            if (RS == 18) launch_mfma_t<18, false>(q, grid, lds_m, st);
+            else if (RS == 34) launch_mfma_t<34, false>(q, grid, lds_m, st);
+            else if (q.G == 1) launch_mfma_t<66, false>(q, grid, lds_m, st);
+            else launch_mfma_t<66, true>(q, grid, lds_m, st);
+            return true;
+        }
+    }
     const bool split = false;
     for (int part = 0; part < 2; ++part) {
         int f0 = a.face0, f1 = a.face0 + nfaces;
@@ -381,7 +649,8 @@ bool launch_mc_region(McArgs a, int nfaces, hipStream_t st) {
             else if (q.G == 1) launch_region_t<66, false, 8>(q, grid, lds, st);
             else launch_region_t<66, true, 8>(q, grid, lds, st);
         } else {
-            if (RS == 34) launch_region_t<34, false, 16>(q, grid, lds, st);
+            if (RS == 18) launch_region_t<18, false, 16>(q, grid, lds, st);
+            else if (RS == 34) launch_region_t<34, false, 16>(q, grid, lds, st);
             else if (q.G == 1) launch_region_t<66, false, 16>(q, grid, lds, st);
             else launch_region_t<66, true, 16>(q, grid, lds, st);
         }
