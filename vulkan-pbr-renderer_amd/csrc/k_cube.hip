@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_prefilter_copy(const float4* __restrict
     const float fu = floorf(u), fv = floorf(v);
     const float a = u - fu, b = v - fv;
     const float nbf = nf + 2.0f;
-    // bordered texel index (face * nb + j0) * nb + i0 with i0 = floor(u) + 1 in [0, n]: exact in fp32 for n <= 1022
+    // bordered texel index (face * nb + j0) * nb + i0 with i0 = floor(u) + 1 in [0, n]: exact in fp32 while 6 (n + 2)^2 < 2^24 (n <= 1600 here)
     const int off = (int)(fmaf(fmaf(fid, nbf, fv + 1.0f), nbf, fu + 1.0f) * 16.0f);
     const int row = (n_src + 2) * 16;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)src_bytes, 0x00020000);
@@ -243,7 +243,7 @@ extern "C" int pbrk_prefilter_copy(const void* src_bordered_level, int n_src, vo
     if (face0 < 0 || face1 > 6 || face0 >= face1 || y0 < 0 || y1 > out_size || y0 >= y1) return PBRK_E_ARG;
     dim3 grid((out_size + 63) / 64, (y1 - y0 + 3) / 4, face1 - face0);
     size_t src_bytes = (size_t)6 * (n_src + 2) * (n_src + 2) * 16;
-    if ((out_size & (out_size - 1)) == 0 && n_src <= 1022)
+    if ((out_size & (out_size - 1)) == 0 && n_src <= 1600)         // 6 (n + 2)^2 < 2^24: the texel index is exact in fp32
         hipLaunchKernelGGL(k_prefilter_copy, grid, dim3(256), 0, (hipStream_t)stream,
                            (const float4*)src_bordered_level, n_src, (unsigned)src_bytes, (float4*)out, out_size, face0, y0, y1 - y0);
     else
