@@ -430,10 +430,10 @@ def main():
         if rank == 0:
             extra["shade_c5"] = c5
 
-    if os.environ.get("PBR_MC_STATS") == "1":
+    if os.environ.get("PBR_MC_STATS") == "1":         # self-check of the region kernel: wave-slices recomputed with direct loads (must be 0)
         st = (C.c_uint64 * 2)()
-        if L.pbrk_mc_stats(st) == 0 and st[1]:
-            extra["mc_binned_fallback_fraction"] = st[0] / st[1]
+        if L.pbrk_mc_region_stats(st, 0) == 0:
+            extra["mc_region_recomputed_wave_slices"] = [int(st[0]), int(st[1])]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

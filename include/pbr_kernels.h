@@ -112,8 +112,6 @@ int pbrk_mc_filter(const void* src_bordered_level, const void* src_cells, int n_
                    float divisor, float alpha, void* out, int out_size,
                    int face0, int face1, int y0, int y1, void* stream);
 
-/* tuning aid (PBR_MC_STATS=1): {wave-samples served by the direct-load fallback, all wave-samples} of the binned K4b kernel */
-int pbrk_mc_stats(unsigned long long* out2);
 /* self-check of the region kernel (PBR_MC_STATS=1): {wave-slices whose sample count came up short and were recomputed with
  * direct loads, all wave-slices}; the first must stay 0.  reset != 0 clears the counters after reading. */
 int pbrk_mc_region_stats(unsigned long long* out2, int reset);

@@ -222,7 +222,6 @@ PROTOTYPES = {
     "pbrk_mc_filter": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, C.c_float, C.c_float, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "pbrk_cells_bytes": (C.c_size_t, [C.c_int]), "pbrk_cells_build": (C.c_int, [VP, C.c_int, VP, VP]),
     "pbrk_shade": (C.c_int, [C.POINTER(PbrkShadeArgs), VP]),
-    "pbrk_mc_stats": (C.c_int, [C.POINTER(C.c_uint64)]),
     "pbrk_mc_region_stats": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
     "pbrk_lut_cells_build": (C.c_int, [VP, C.c_int, VP, VP]),
     "pbrk_equirect_to_cube": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, VP]),
