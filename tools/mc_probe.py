@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time pbrk_mc_filter (K4b) on synthetic levels: picoseconds per sample evaluation and clocks per wave-sample per CU for a
 given (n_src, out_size, roughness).  Kernel choice follows the library (env PBR_MC_LDS / PBR_MC_REGION / PBR_MC_BINNED).
-   python3 tools/mc_probe.py n_src out_size [roughness] [rows]"""
+   python3 tools/mc_probe.py n_src out_size [roughness] [rows] [face0 face1]"""
 import ctypes as C
 import os
 import sys
@@ -18,6 +18,7 @@ def main():
     n_src, out = int(sys.argv[1]), int(sys.argv[2])
     rough = float(sys.argv[3]) if len(sys.argv) > 3 else 0.15
     rows = int(sys.argv[4]) if len(sys.argv) > 4 else out
+    f0, f1 = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (0, 6)
     L = pbrhip.init(0)
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(1)
@@ -38,7 +39,7 @@ def main():
 
     def run():
         rc = L.pbrk_mc_filter(bord.data_ptr(), cells.data_ptr() if use_cells else None, n_src, dtab.data_ptr(), n_tab,
-                              float(np.pi), alpha.value, outt.data_ptr(), out, 0, 6, 0, rows, None)
+                              float(np.pi), alpha.value, outt.data_ptr(), out, f0, f1, 0, rows, None)
         assert rc == 0, rc
 
     run(); torch.cuda.synchronize()
@@ -48,11 +49,11 @@ def main():
         a.record(); run(); b.record(); torch.cuda.synchronize()
         ts.append(a.elapsed_time(b))
     ms = min(ts)
-    evals = 6.0 * out * rows * n_tab
+    evals = float(f1 - f0) * out * rows * n_tab
     ps = ms * 1e-3 / evals * 1e12
     clk = ps * 1e-12 * 256 * 2.4e9 * 64
     chk = float(outt[:, :rows].double().sum().item())
-    print(f"n_src {n_src} out {out} rows {rows} n_tab {n_tab}: {ms:.3f} ms  {ps:.3f} ps/eval  {clk:.1f} clk per wave-sample per CU @2.4GHz  "
+    print(f"n_src {n_src} out {out} rows {rows} faces {f0}-{f1} n_tab {n_tab}: {ms:.3f} ms  {ps:.3f} ps/eval  {clk:.1f} clk per wave-sample per CU @2.4GHz  "
           f"{65 * evals / ms * 1e-9:.1f} TFLOP/s alg  checksum {chk:.6e}", flush=True)
     if os.environ.get("PBR_MC_STATS") == "1":
         st = (C.c_uint64 * 2)()

@@ -220,7 +220,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const int s = __builtin_amdgcn_readfirstlane(tid / REG_TX);
     const int t = tid % REG_TX;
 
-    unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    // Tiles in plain block order: consecutive tiles go round-robin over the 8 XCDs.  An XCD-contiguous remap (one eighth of the
+    // grid per XCD) put all tiles around the pole of the tangent frame -- where every sample is flagged for several regions and a tile
+    // takes up to 3x as long -- on ONE XCD, and the launch waited for it (a single-face dispatch of a +-X face: 10.2 vs 7.6 ms).
+    // The whole level fits every XCD's L2, so locality has nothing to lose.
+    unsigned tile = blockIdx.x;
     const int face = p.face0 + (int)(tile / (unsigned)p.tiles_per_face);
     const int tf = (int)(tile % (unsigned)p.tiles_per_face);
     const int ty = tf / p.tiles_x, tx = tf % p.tiles_x;
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, row = lane & 15, g = lane >> 4;
 
-    unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    unsigned tile = blockIdx.x;                                    // plain order: see k_mc_region
     const int face = p.face0 + (int)(tile / (unsigned)p.tiles_per_face);
     const int tf = (int)(tile % (unsigned)p.tiles_per_face);
     const int ty = tf / p.tiles_x, tx = tf % p.tiles_x;

@@ -206,11 +206,12 @@ static double time_weight(const PBR_WorkUnit* u) {
 
 /* Faces 0 and 1 (+-X) contain the pole of the tangent frame (`some_vector`): neighbouring texels there take their samples at
  * different azimuths, so the lanes of a wave spread one sample over several regions of the source level and the tile's region
- * flags are wider.  Run alone, single-face dispatches of the region kernel take 1.27x, 1.30x, 2.0x as long there for mips 1-3
- * (tools/face_time.py, C4); next to other dispatches roughly two thirds of the excess remains, which is what balances the shares
- * of a 4- and 8-way split (tools/rank_time.py). */
+ * flags are wider.  Run alone, single-face dispatches of the region kernel take 1.09x, 1.07x, 1.7x as long there for mips 1-3
+ * (tools/face_time.py, C4; with tiles dealt round-robin over the XCDs -- an XCD-contiguous tile order had 1.23x / 1.23x / 1.9x
+ * because the slow tiles around the pole all sat on one XCD); the weights below balance the shares of a 4- and 8-way split
+ * (tools/rank_time.py). */
 static double face_weight(const PBR_WorkUnit* u, uint32_t face) {
-    static const double pole[6] = {1.0, 1.10, 1.12, 1.3, 1.1, 1.05};
+    static const double pole[6] = {1.0, 1.06, 1.06, 1.3, 1.1, 1.05};
     if (u->kind != PBR_Unit_Prefilter || face > 1 || u->mip > 5) return 1.0;
     return pole[u->mip];
 }
