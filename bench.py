@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--no-shade", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="skip the 7680x4320 screen-band shade leg (extra.shade_c5)")
     ap.add_argument("--c5-frames", type=int, default=10)
+    ap.add_argument("--overlap", action="store_true", default=os.environ.get("PBR_BENCH_OVERLAP", "0") == "1",
+                    help="record the job as two graphs (mip-1 units first) and send each part while the next computes (PBR_RunPartitionedIBL; "
+                         "needs the C gather for N > 1; opt-in: never run on more than one GPU)")
     ap.add_argument("--check", action="store_true", help="after the run, spot-check output texels against the oracle")
     args = ap.parse_args()
 
@@ -236,6 +239,8 @@ def main():
     pipes = L.PBR_MakeIBLPipelines()
     arena = L.GPU_MakeDescriptorArena()
     graph = L.GPU_MakeGraph()
+    graph2 = L.GPU_MakeGraph() if args.overlap else None
+    overlap = bool(args.overlap and (world == 1 or comm is not None))
 
     # the exchange is the same every step: the send/recv descriptors (views of the output memory) are built once
     gather_ops, staged = [], []
@@ -258,6 +263,16 @@ def main():
     def step():
         t_a = time.perf_counter()
         L.GPU_OpGenerateMipmaps(graph, env_tex)                                   # K2 (+ apron rebuild on first sample)
+        if overlap:                                                               # two graphs, each followed by its share of the exchange
+            moved = L.PBR_RunPartitionedIBL(pipes, graph, graph2, arena, env_tex, C.byref(maps), comm, 0, world, rank, 1, 0x2)
+            if moved < 0:
+                raise RuntimeError(f"PBR_RunPartitionedIBL failed ({moved})")
+            L.GPU_GraphWait(graph2); L.GPU_GraphWait(graph)
+            L.GPU_ResetDescriptorArena(arena)
+            t_b = time.perf_counter()
+            k_s = sum(L.GPUX_GraphTimedOpMs(g_, i) for g_ in (graph, graph2) for i in range(L.GPUX_GraphTimedOpCount(g_))) * 1e-3
+            phase["compute"] += min(k_s, t_b - t_a); phase["exchange"] += max(0.0, t_b - t_a - k_s)
+            return
         L.PBR_RecordUnits(pipes, graph, arena, env_tex, C.byref(maps), my_units, n_my)
         L.GPU_GraphSubmit(graph)
         if comm is not None:                                                      # the exchange follows the kernels on the graph's own stream
@@ -300,9 +315,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        for i in range(L.GPUX_GraphTimedOpCount(graph)):
-            nm = L.GPUX_GraphTimedOpName(graph, i).decode()
-            op_ms.setdefault(nm, []).append(L.GPUX_GraphTimedOpMs(graph, i))
+        for g_ in ((graph, graph2) if overlap else (graph,)):
+            for i in range(L.GPUX_GraphTimedOpCount(g_)):
+                nm = L.GPUX_GraphTimedOpName(g_, i).decode()
+                op_ms.setdefault(nm, []).append(L.GPUX_GraphTimedOpMs(g_, i))
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -318,7 +334,7 @@ def main():
         step_split = {"compute_ms_per_step_by_rank": [float(g[0]) / args.steps * 1e3 for g in gathered],
                       "exchange_ms_per_step_by_rank": [float(g[1]) / args.steps * 1e3 for g in gathered],
                       "bytes_sent_by_rank": [0] + [int(sum(unit_slice(*u).numel() * 4 for u in all_units[r])) for r in range(1, world)],
-                      "gather": gather_impl}
+                      "gather": gather_impl + (" in two overlapped phases (PBR_RunPartitionedIBL, mip 1 first)" if overlap else "")}
 
     total_texels = sum(6 * max(1, spec_size >> m) ** 2 for m in range(n_mips)) + 6 * irr_size * irr_size
     ms_per_step = elapsed / args.steps * 1e3
@@ -479,7 +495,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "env": f"procedural HDR cube {W}^2 x6 RGBA32F (seed {seed:#x}, RGBE round-tripped)",
                        "texels_per_step": total_texels, "sample_evaluations_per_step": sample_evals,
-                       "parallelism": "single GPU" if world == 1 else f"{world} ranks, weighted linear partition of output rows (3-8 dispatches per rank), 1 grouped RCCL send/recv gather per step"},
+                       "overlap": overlap, "parallelism": "single GPU" if world == 1 else f"{world} ranks, weighted linear partition of output rows (3-8 dispatches per rank), 1 grouped RCCL send/recv gather per step"},
             "roofline": roofline, "roofline_hbm": roofline_hbm, "rates": rates, "step_split": step_split, "kernels": kernels[:12],
             "cpu_baseline": cpu, "extra": extra,
         }

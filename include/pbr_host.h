@@ -91,6 +91,25 @@ int PBR_UnitByteRange(const PBR_IBLMaps* maps, const PBR_WorkUnit* unit, GPU_Tex
  * min_size / env_size it partitioned with.  Returns the bytes this rank sent or received (0 when world == 1). */
 int64_t PBR_GatherUnits(void* nccl_comm, void* stream, int root, int world, int rank, const PBR_IBLMaps* maps,
                         uint32_t min_size, uint32_t env_size);
+/* The same for a subset of the levels: bit l of level_mask = prefilter mip l, PBR_LEVEL_IRRADIANCE = the irradiance map.
+ * All ranks must call the phases in the same order (one communicator: RCCL keeps issue order). */
+#define PBR_LEVEL_IRRADIANCE 0x80000000u
+int64_t PBR_GatherUnitsMasked(void* nccl_comm, void* stream, int root, int world, int rank, const PBR_IBLMaps* maps,
+                              uint32_t min_size, uint32_t env_size, uint32_t level_mask);
+/* The transfers PBR_GatherUnitsMasked would enqueue for `rank` (root: receives from every peer; others: sends to root), without
+ * a communicator: out may be NULL to count.  Returns the number of ranges. */
+int64_t PBR_GatherPlan(int root, int world, int rank, const PBR_IBLMaps* maps, uint32_t min_size, uint32_t env_size,
+                       uint32_t level_mask, PBR_XferRange* out, uint32_t capacity);
+/* units[i] whose level is in level_mask, in order; out may alias nothing; returns the count */
+uint32_t PBR_SelectUnits(const PBR_WorkUnit* units, uint32_t n, uint32_t level_mask, PBR_WorkUnit* out);
+/* One rank's whole share with the exchange overlapped: the units of `early_mask` (the level that is most bytes on the wire: mip 1,
+ * i.e. early_mask = 2) are recorded into g_early behind whatever the caller already recorded there (the source's
+ * GPU_OpGenerateMipmaps), the rest into g_late; both are submitted, then the early units travel on g_early's stream while
+ * g_late computes, the late ones follow g_late.  The caller waits: GPU_GraphWait(g_late); GPU_GraphWait(g_early); and resets
+ * the arena.  world == 1 runs both graphs and moves nothing.  Returns bytes sent / received by this rank, or PBR_E_*. */
+int64_t PBR_RunPartitionedIBL(PBR_IBLPipelines* p, GPU_Graph* g_early, GPU_Graph* g_late, GPU_DescriptorArena* arena,
+                              GPU_Texture* tex_env_cube, const PBR_IBLMaps* maps, void* nccl_comm, int root, int world, int rank,
+                              uint32_t min_size, uint32_t early_mask);
 /* Screen-band split of the shade pass (C5): rank r owns rows [height*r/world, height*(r+1)/world) of the frame */
 void PBR_BandRows(uint32_t height, int world, int rank, uint32_t* row0, uint32_t* row1);
 int64_t PBR_GatherBands(void* nccl_comm, void* stream, int root, int world, int rank, GPU_Texture* frame);

@@ -149,3 +149,107 @@ def test_invalidate_texture_after_external_write(gpu):
     L.PBR_GenIrradianceMap(ext, out)
     assert np.array_equal(pbrhip.read_mip(out, 0), ref["B"])
     L.GPU_DestroyGraph(g); L.GPU_DestroyTexture(out); L.GPU_DestroyTexture(ext); L.GPU_DestroyBuffer(store)
+
+
+def test_overlapped_partitioned_run_equals_sequential(gpu):
+    """PBR_RunPartitionedIBL (two graphs: the units of the early levels, then the rest; each followed by its exchange) on world = 1:
+    both graphs run, nothing moves, and the maps equal the sequential PBR_Gen* result bit for bit -- for the default early level
+    (mip 1), for an early set that holds most of the job, and for an empty one."""
+    import pbrhip
+    from pbrhip import synth
+    L = gpu
+    env = synth.synth_env(64, seed=0x5EED00AC)
+    tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, 64, 64, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+    maps = pbrhip.PBR_IBLMaps()
+    L.PBR_MakeIBLMaps(C.byref(maps), 16, 64, 128)
+    spec, irr = maps.tex_specular_env_map, maps.irradiance_map
+    n_mips = spec.contents.mip_level_count
+    L.PBR_GenPrefilteredEnvMap(tex, spec, 1); L.PBR_GenIrradianceMap(tex, irr)
+    want = [pbrhip.read_mip(spec, m).copy() for m in range(n_mips)] + [pbrhip.read_mip(irr, 0).copy()]
+    gA, gB, gC = L.GPU_MakeGraph(), L.GPU_MakeGraph(), L.GPU_MakeGraph()
+    pipes = L.PBR_MakeIBLPipelines(); arena = L.GPU_MakeDescriptorArena()
+    for early in (0x2, 0x80000006, 0x0):
+        for m in range(n_mips):
+            L.GPU_OpClearColorF(gC, spec, m, 0.0, 0.0, 0.0, 0.0)
+        L.GPU_OpClearColorF(gC, irr, 0, 0.0, 0.0, 0.0, 0.0)
+        L.GPU_GraphSubmit(gC); L.GPU_GraphWait(gC)
+        L.GPU_OpGenerateMipmaps(gA, tex)                              # the caller's prologue rides in the early graph
+        moved = L.PBR_RunPartitionedIBL(pipes, gA, gB, arena, tex, C.byref(maps), None, 0, 1, 0, 1, early)
+        assert moved == 0
+        L.GPU_GraphWait(gB); L.GPU_GraphWait(gA); L.GPU_ResetDescriptorArena(arena)
+        got = [pbrhip.read_mip(spec, m) for m in range(n_mips)] + [pbrhip.read_mip(irr, 0)]
+        for m, (a, b) in enumerate(zip(got, want)):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (hex(early), m)
+    assert L.PBR_RunPartitionedIBL(pipes, gA, gA, arena, tex, C.byref(maps), None, 0, 1, 0, 1, 2) == -1      # one graph twice
+    assert L.PBR_RunPartitionedIBL(pipes, gA, gB, arena, tex, C.byref(maps), None, 0, 2, 1, 1, 2) == -1      # world 2 without a communicator
+    for g in (gA, gB, gC):
+        L.GPU_DestroyGraph(g)
+    L.GPU_DestroyDescriptorArena(arena); L.PBR_DestroyIBLPipelines(pipes)
+    L.PBR_DestroyIBLMaps(C.byref(maps)); L.GPU_DestroyTexture(tex)
+
+
+def test_gather_phases_cover_the_exchange_once_and_run_on_two_streams(gpu):
+    """The two phases of the overlapped exchange (PBR_GatherPlan with the early mask and with its complement) are disjoint and
+    together equal the one-shot plan, on the sending ranks and on the root (whose receives mirror the peers' sends); then the
+    phases of every rank of a 3-way split run as two grouped RCCL exchanges on two different streams of a 1-rank communicator
+    (to self, into a second buffer) and every unit arrives bit-identical."""
+    import pbrhip
+    L = gpu
+    tex, maps = _maps_32(L, pbrhip)
+    spec = maps.tex_specular_env_map
+    ALL, EARLY = 0xFFFFFFFF, 0x2
+
+    def plan(world, rank, mask):
+        cap = 4096
+        xs = (pbrhip.PBR_XferRange * cap)()
+        n = L.PBR_GatherPlan(0, world, rank, C.byref(maps), 1, 32, mask, xs, cap)
+        assert n >= 0 and n == L.PBR_GatherPlan(0, world, rank, C.byref(maps), 1, 32, mask, None, 0)
+        return [(xs[i].ptr, xs[i].bytes, xs[i].peer) for i in range(n)]
+
+    for world in (2, 3, 8):
+        sends = {}
+        for r in range(1, world):
+            a, e, l = plan(world, r, ALL), plan(world, r, EARLY), plan(world, r, ~EARLY & ALL)
+            assert sorted(e + l) == sorted(a) and not set(e) & set(l) and all(p == 0 for (_, _, p) in a)
+            ivs = sorted((p_, p_ + b) for (p_, b, _) in a)
+            assert all(x[1] <= y[0] for x, y in zip(ivs, ivs[1:]))            # ranges of one rank do not overlap
+            sends[r] = a
+        for mask in (ALL, EARLY, ~EARLY & ALL):
+            root = plan(world, 0, mask)
+            peers = sorted((p_, b, r) for r in range(1, world) for (p_, b, _) in plan(world, r, mask))
+            assert sorted(root) == peers                                       # root receives exactly what the peers send, in place
+        units0, n0 = pbrhip.partition(32, 1, 8, 32, world, 0)
+        assert n0 > 0 and plan(1, 0, ALL) == []
+    # run the phases of ranks 1 and 2 of the 3-way split: early on stream A, late on stream B, one communicator
+    comm = pbrhip.rccl_comm_init(1, 0, pbrhip.rccl_unique_id())
+    try:
+        gA, gB = L.GPU_MakeGraph(), L.GPU_MakeGraph()
+        nbytes = L.GPUX_TextureTotalBytes(spec)
+        dst = L.GPU_MakeBuffer(nbytes, pbrhip.BufferFlag_GPU, None); host = L.GPU_MakeBuffer(nbytes, pbrhip.BufferFlag_CPU, None)
+        zbuf = L.GPU_MakeBuffer(nbytes, pbrhip.BufferFlag_CPU, np.zeros(nbytes, np.uint8).ctypes.data_as(C.c_void_p))
+        L.GPU_OpCopyBufferToBuffer(gA, zbuf, dst, 0, 0, nbytes); L.GPU_GraphSubmit(gA); L.GPU_GraphWait(gA)
+        src0, dst0 = L.GPUX_TextureDevicePtr(spec, 0), L.GPUX_BufferDevicePtr(dst)
+        covered = np.zeros(nbytes, bool)
+        for g, mask in ((gA, EARLY), (gB, ~EARLY & ALL)):
+            S, R = [], []
+            for r in (1, 2):
+                for (p_, b, _) in plan(3, r, mask):
+                    off = p_ - src0
+                    if not (0 <= off < nbytes):
+                        continue                                             # irradiance units live in another texture
+                    S.append(pbrhip.PBR_XferRange(p_, b, 0)); R.append(pbrhip.PBR_XferRange(dst0 + off, b, 0)); covered[off:off + b] = True
+            assert S
+            Sa, Ra = (pbrhip.PBR_XferRange * len(S))(*S), (pbrhip.PBR_XferRange * len(R))(*R)
+            assert L.PBR_ExchangeRanges(comm, L.GPUX_GraphStream(g), Sa, len(S), Ra, len(R)) == 0
+        L.GPU_GraphSubmit(gA); L.GPU_GraphSubmit(gB)                           # empty graphs: B is ordered after A's stream, exchanges included
+        L.GPU_GraphWait(gB); L.GPU_GraphWait(gA)
+        L.GPU_OpCopyBufferToBuffer(gA, dst, host, 0, 0, nbytes); L.GPU_GraphSubmit(gA); L.GPU_GraphWait(gA)
+        got = np.frombuffer((C.c_char * nbytes).from_address(host.contents.data), np.uint8)
+        want = np.concatenate([pbrhip.read_mip(spec, m).view(np.uint8).ravel() for m in range(spec.contents.mip_level_count)])
+        assert covered.any() and np.array_equal(got[covered], want[covered]) and not got[~covered].any()
+        for b_ in (dst, host, zbuf):
+            L.GPU_DestroyBuffer(b_)
+        L.GPU_DestroyGraph(gA); L.GPU_DestroyGraph(gB)
+    finally:
+        pbrhip.rccl_comm_destroy(comm)
+    L.PBR_DestroyIBLMaps(C.byref(maps)); L.GPU_DestroyTexture(tex)

@@ -258,6 +258,39 @@ if rank == 0:                                                       # gathered =
     assert np.array_equal(imem.numpy().view(np.uint32), O.irradiance(pyr, W, irr).ravel().view(np.uint32)), "gathered irradiance differs"
     print("GATHER_OK", int(total))
 dist.barrier()
+# --- the overlapped form (PBR_RunPartitionedIBL's schedule): the units of the early levels (PBR_SelectUnits, mask = mip 1) are
+# computed first and are on the wire while the rest is computed; two grouped exchanges, every rank issues them in the same order
+import ctypes as C
+mem.zero_(); imem.zero_()
+EARLY = 0x2
+def select(us, m, mask):
+    out = (pbrhip.PBR_WorkUnit * max(1, m))()
+    k = L.PBR_SelectUnits(us, m, mask & 0xFFFFFFFF, out)
+    return [out[i] for i in range(k)]
+early, late = select(mine, n, EARLY), select(mine, n, ~EARLY)
+assert len(early) + len(late) == n and all(u.kind == pbrhip.Unit_Prefilter and u.mip == 1 for u in early)
+def exchange(mask, my_units):
+    if rank == 0:
+        ops = []
+        for r in range(1, world):
+            us, m = pbrhip.partition(spec, 1, irr, W, world, r)
+            ops += [dist.P2POp(dist.irecv, sl(u), r) for u in select(us, m, mask)]
+    else:
+        ops = [dist.P2POp(dist.isend, sl(u), 0) for u in my_units]
+    return dist.batch_isend_irecv(ops) if ops else []
+for u in early:
+    sl(u).copy_(torch.from_numpy(compute(u)))
+pending = exchange(EARLY, early)                                    # in flight ...
+for u in late:                                                      # ... while the rest is computed
+    sl(u).copy_(torch.from_numpy(compute(u)))
+pending += exchange(~EARLY, late)
+for w in pending:
+    w.wait()
+if rank == 0:
+    assert np.array_equal(mem.numpy().view(np.uint32), want.view(np.uint32)), "two-phase gather: specular pyramid differs"
+    assert np.array_equal(imem.numpy().view(np.uint32), O.irradiance(pyr, W, irr).ravel().view(np.uint32)), "two-phase gather: irradiance differs"
+    print("OVERLAP_OK")
+dist.barrier()
 dist.destroy_process_group()
 """
 
@@ -265,14 +298,15 @@ dist.destroy_process_group()
 def test_two_rank_gloo_gather(L, tmp_path):
     """The N>1 data path (PBR_PartitionIBL -> per-rank units -> one grouped send/recv gather of the units' byte ranges to rank 0)
     on CPU with gloo standing in for RCCL and the oracle standing in for the kernels: the gathered maps equal the whole job
-    computed in one piece, bit for bit."""
+    computed in one piece, bit for bit -- once as one exchange after all units, once in the two overlapped phases of
+    PBR_RunPartitionedIBL (early levels on the wire while the late ones are computed)."""
     script = tmp_path / "gloo_worker.py"
     script.write_text(GLOO_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", "29533", str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "GATHER_OK" in out.stdout
+    assert "GATHER_OK" in out.stdout and "OVERLAP_OK" in out.stdout
 
 
 def test_unorm8_decode_trick():

@@ -61,43 +61,109 @@ int PBR_ExchangeRanges(void* nccl_comm, void* stream, const PBR_XferRange* sends
 /* unit lists are small (tens of units per rank) */
 #define MAX_UNITS 512
 
-int64_t PBR_GatherUnits(void* nccl_comm, void* stream, int root, int world, int rank, const PBR_IBLMaps* maps,
-                        uint32_t min_size, uint32_t env_size) {
+/* bit of a unit in a level mask: prefilter mip l = bit l, irradiance = PBR_LEVEL_IRRADIANCE */
+static uint32_t unit_level_bit(const PBR_WorkUnit* u) {
+    if (u->kind == PBR_Unit_Irradiance) return PBR_LEVEL_IRRADIANCE;
+    if (u->kind == PBR_Unit_Prefilter) return u->mip < 31 ? (1u << u->mip) : 0u;
+    return 0u;
+}
+
+uint32_t PBR_SelectUnits(const PBR_WorkUnit* units, uint32_t n, uint32_t level_mask, PBR_WorkUnit* out) {
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < n; ++i) if (unit_level_bit(&units[i]) & level_mask) out[k++] = units[i];
+    return k;
+}
+
+int64_t PBR_GatherPlan(int root, int world, int rank, const PBR_IBLMaps* maps, uint32_t min_size, uint32_t env_size,
+                       uint32_t level_mask, PBR_XferRange* out, uint32_t capacity) {
     if (!maps || !maps->tex_specular_env_map || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world) return PBR_E_BADARG;
     if (world == 1) return 0;
-    if (!nccl_comm) return PBR_E_BADARG;
     const uint32_t spec = maps->tex_specular_env_map->width;
     const uint32_t irr = maps->irradiance_map ? maps->irradiance_map->width : 0;
     PBR_WorkUnit* units = (PBR_WorkUnit*)malloc(sizeof(PBR_WorkUnit) * MAX_UNITS);
-    PBR_XferRange* xf = (PBR_XferRange*)malloc(sizeof(PBR_XferRange) * MAX_UNITS * (size_t)(rank == root ? world : 1));
-    if (!units || !xf) { free(units); free(xf); return PBR_E_BADARG; }
+    if (!units) return PBR_E_BADARG;
     uint32_t n_xf = 0;
-    int64_t total = 0;
     int rc = PBR_OK;
     for (int r = 0; r < world && rc == PBR_OK; ++r) {
         if (r == root || (rank != root && r != rank)) continue;           /* the root's own units are already in place */
         uint32_t n = PBR_PartitionIBL(spec, min_size, irr, env_size, world, r, units, MAX_UNITS);
         for (uint32_t k = 0; k < n; ++k) {
-            if (units[k].kind == PBR_Unit_BrdfLut) continue;              /* computed redundantly on every rank */
+            if (!(unit_level_bit(&units[k]) & level_mask)) continue;      /* other phase; the BRDF LUT is computed redundantly on every rank */
             GPU_Texture* t; uint64_t off, bytes;
             rc = PBR_UnitByteRange(maps, &units[k], &t, &off, &bytes);
             if (rc != PBR_OK) break;
-            xf[n_xf].ptr = (char*)GPUX_TextureDevicePtr(t, 0) + off;
-            xf[n_xf].bytes = bytes;
-            xf[n_xf].peer = rank == root ? r : root;
-            total += (int64_t)bytes;
+            if (out) {
+                if (n_xf >= capacity) { rc = PBR_E_BADARG; break; }
+                out[n_xf].ptr = (char*)GPUX_TextureDevicePtr(t, 0) + off;
+                out[n_xf].bytes = bytes;
+                out[n_xf].peer = rank == root ? r : root;
+            }
             ++n_xf;
         }
     }
-    if (rc == PBR_OK)
-        rc = rank == root ? PBR_ExchangeRanges(nccl_comm, stream, NULL, 0, xf, n_xf) : PBR_ExchangeRanges(nccl_comm, stream, xf, n_xf, NULL, 0);
-    if (rc == PBR_OK && rank == root) {
+    free(units);
+    return rc == PBR_OK ? (int64_t)n_xf : rc;
+}
+
+int64_t PBR_GatherUnitsMasked(void* nccl_comm, void* stream, int root, int world, int rank, const PBR_IBLMaps* maps,
+                              uint32_t min_size, uint32_t env_size, uint32_t level_mask) {
+    if (!maps || !maps->tex_specular_env_map || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world) return PBR_E_BADARG;
+    if (world == 1) return 0;
+    if (!nccl_comm) return PBR_E_BADARG;
+    const uint32_t cap = MAX_UNITS * (uint32_t)(rank == root ? world : 1);
+    PBR_XferRange* xf = (PBR_XferRange*)malloc(sizeof(PBR_XferRange) * (size_t)cap);
+    if (!xf) return PBR_E_BADARG;
+    int64_t n = PBR_GatherPlan(root, world, rank, maps, min_size, env_size, level_mask, xf, cap);
+    int64_t total = 0;
+    int rc = n < 0 ? (int)n : PBR_OK;
+    if (rc == PBR_OK) {
+        for (int64_t i = 0; i < n; ++i) total += (int64_t)xf[i].bytes;
+        rc = rank == root ? PBR_ExchangeRanges(nccl_comm, stream, NULL, 0, xf, (uint32_t)n) : PBR_ExchangeRanges(nccl_comm, stream, xf, (uint32_t)n, NULL, 0);
+    }
+    if (rc == PBR_OK && rank == root && n > 0) {
         /* the received bytes bypass the backend's op recording: drop the sampler twins built from the old contents */
         GPUX_InvalidateTexture(maps->tex_specular_env_map);
         if (maps->irradiance_map) GPUX_InvalidateTexture(maps->irradiance_map);
     }
-    free(units); free(xf);
+    free(xf);
     return rc == PBR_OK ? total : rc;
+}
+
+int64_t PBR_GatherUnits(void* nccl_comm, void* stream, int root, int world, int rank, const PBR_IBLMaps* maps,
+                        uint32_t min_size, uint32_t env_size) {
+    return PBR_GatherUnitsMasked(nccl_comm, stream, root, world, rank, maps, min_size, env_size, 0xFFFFFFFFu);
+}
+
+/* The whole partitioned job of one rank with the exchange overlapped (see pbr_host.h).  Two graphs, two exchanges:
+ *   g_early: [whatever the caller recorded: the source's mip chain] + the units of `early_mask`   -> submit
+ *   g_late : the remaining units                                                                 -> submit (ordered after g_early's kernels)
+ *   exchange of the early units on g_early's stream: starts when g_early's kernels are done, runs beside g_late's kernels
+ *   exchange of the late units on g_late's stream
+ * Root receives into ranges no kernel of its own writes (units are disjoint), so the transfers need no further fencing. */
+int64_t PBR_RunPartitionedIBL(PBR_IBLPipelines* p, GPU_Graph* g_early, GPU_Graph* g_late, GPU_DescriptorArena* arena,
+                              GPU_Texture* tex_env_cube, const PBR_IBLMaps* maps, void* nccl_comm, int root, int world, int rank,
+                              uint32_t min_size, uint32_t early_mask) {
+    if (!p || !g_early || !g_late || g_early == g_late || !arena || !tex_env_cube || !maps || !maps->tex_specular_env_map ||
+        world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || (world > 1 && !nccl_comm)) return PBR_E_BADARG;
+    const uint32_t spec = maps->tex_specular_env_map->width;
+    const uint32_t irr = maps->irradiance_map ? maps->irradiance_map->width : 0;
+    const uint32_t env_size = tex_env_cube->width;
+    PBR_WorkUnit* units = (PBR_WorkUnit*)malloc(sizeof(PBR_WorkUnit) * MAX_UNITS * 2);
+    if (!units) return PBR_E_BADARG;
+    PBR_WorkUnit* part = units + MAX_UNITS;
+    uint32_t n = PBR_PartitionIBL(spec, min_size, irr, env_size, world, rank, units, MAX_UNITS);
+    uint32_t ne = PBR_SelectUnits(units, n, early_mask, part);
+    if (ne) PBR_RecordUnits(p, g_early, arena, tex_env_cube, maps, part, ne);
+    GPU_GraphSubmit(g_early);
+    uint32_t nl = PBR_SelectUnits(units, n, ~early_mask, part);
+    if (nl) PBR_RecordUnits(p, g_late, arena, tex_env_cube, maps, part, nl);
+    GPU_GraphSubmit(g_late);
+    free(units);
+    int64_t b0 = PBR_GatherUnitsMasked(nccl_comm, GPUX_GraphStream(g_early), root, world, rank, maps, min_size, env_size, early_mask);
+    if (b0 < 0) return b0;
+    int64_t b1 = PBR_GatherUnitsMasked(nccl_comm, GPUX_GraphStream(g_late), root, world, rank, maps, min_size, env_size, ~early_mask);
+    if (b1 < 0) return b1;
+    return b0 + b1;
 }
 
 void PBR_BandRows(uint32_t height, int world, int rank, uint32_t* row0, uint32_t* row1) {

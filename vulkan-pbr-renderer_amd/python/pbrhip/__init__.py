@@ -186,6 +186,10 @@ PROTOTYPES = {
     "PBR_ExchangeRanges": (C.c_int, [VP, VP, VP, U32, VP, U32]),
     "PBR_UnitByteRange": (C.c_int, [C.POINTER(PBR_IBLMaps), C.POINTER(PBR_WorkUnit), C.POINTER(TexP), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "PBR_GatherUnits": (C.c_int64, [VP, VP, C.c_int, C.c_int, C.c_int, C.POINTER(PBR_IBLMaps), U32, U32]),
+    "PBR_GatherUnitsMasked": (C.c_int64, [VP, VP, C.c_int, C.c_int, C.c_int, C.POINTER(PBR_IBLMaps), U32, U32, U32]),
+    "PBR_GatherPlan": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.POINTER(PBR_IBLMaps), U32, U32, U32, VP, U32]),
+    "PBR_SelectUnits": (U32, [C.POINTER(PBR_WorkUnit), U32, U32, C.POINTER(PBR_WorkUnit)]),
+    "PBR_RunPartitionedIBL": (C.c_int64, [VP, VP, VP, VP, TexP, C.POINTER(PBR_IBLMaps), VP, C.c_int, C.c_int, C.c_int, U32, U32]),
     "PBR_BandRows": (None, [U32, C.c_int, C.c_int, C.POINTER(U32), C.POINTER(U32)]),
     "PBR_GatherBands": (C.c_int64, [VP, VP, C.c_int, C.c_int, C.c_int, TexP]),
     "PBR_FillGlobals": (None, [C.POINTER(PBR_Globals), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float,
