@@ -9,6 +9,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "vulkan-pbr-ren
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the region kernel's self-check counters (wave-slices that had to be recomputed with direct loads: must stay 0) are on for the tests
+os.environ.setdefault("PBR_MC_STATS", "1")
 
 
 def pytest_configure(config):

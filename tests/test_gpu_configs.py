@@ -50,6 +50,50 @@ def test_c4_textured_environment_oracle_rows(gpu, c4_env):
     L.GPU_DestroyTexture(irr); L.GPU_DestroyTexture(spec); L.GPU_DestroyTexture(tex)
 
 
+def test_region_kernel_ragged_row_shards_equal_full(gpu, c2_env, c4_env):
+    """K4b's region kernel (taps from LDS-staged regions; levels with a source of >= 16^2 and an output of >= 256^2) in all its
+    shapes -- 18^2 / 34^2 / 66^2 whole-face regions and 66^2 quarter-face regions -- dispatched as ragged row shards (rows that
+    are no multiple of the 16-row tile, three shards per face) reproduces the whole-level dispatch bit for bit, and no wave had to
+    fall back to direct loads (its completeness self-check).  Oracle parity of the same levels: test_c4_* / test_c2_*."""
+    import pbrhip
+    from pbrhip import synth
+    L = gpu
+    st = (C.c_uint64 * 2)()
+    assert L.pbrk_mc_region_stats(st, 1) in (0, -1)                     # reset (available once the kernel has run with PBR_MC_STATS=1)
+    env256 = synth.synth_env(256, seed=0x5EED00AD)
+    cases = ((env256, 256, 512, (1,)),            # mip 1: 256^2 from a 16^2 level  -> 18^2 regions
+             (c2_env, 1024, 1024, (1, 2)),        # mip 1: 512^2 from 64^2 -> 66^2 whole-face; mip 2: 256^2 from 32^2 -> 34^2
+             (c4_env, 2048, 512, (1,)))           # mip 1: 256^2 from 128^2 -> 66^2 quarter-face regions
+    pipes = L.PBR_MakeIBLPipelines(); arena = L.GPU_MakeDescriptorArena(); g = L.GPU_MakeGraph()
+    for env, W, S, mips in cases:
+        tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, W, W, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+        maps = pbrhip.PBR_IBLMaps()
+        L.PBR_MakeIBLMaps(C.byref(maps), 8, 64, S)
+        spec = maps.tex_specular_env_map
+        L.PBR_GenPrefilteredEnvMap(tex, spec, 256)
+        full = {m: pbrhip.read_mip(spec, m).copy() for m in mips}
+        for m in mips:
+            L.GPU_OpClearColorF(g, spec, m, 0.0, 0.0, 0.0, 0.0)
+        L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+        units = []
+        for m in mips:
+            size = S >> m
+            for f in range(6):
+                cuts = (0, 5 + f, 131 - 2 * f, size)
+                units += [pbrhip.PBR_WorkUnit(pbrhip.Unit_Prefilter, m, f, f + 1, cuts[k], cuts[k + 1], 0.0) for k in range(3)]
+        arr = (pbrhip.PBR_WorkUnit * len(units))(*units)
+        L.PBR_RecordUnits(pipes, g, arena, tex, C.byref(maps), arr, len(units))
+        L.GPU_GraphSubmit(g); L.GPU_GraphWait(g); L.GPU_ResetDescriptorArena(arena)
+        for m in mips:
+            got = pbrhip.read_mip(spec, m)
+            assert np.array_equal(got.view(np.uint32), full[m].view(np.uint32)), (W, S, m)
+            assert float(np.abs(got[..., :3]).max()) > 0.0
+        L.PBR_DestroyIBLMaps(C.byref(maps)); L.GPU_DestroyTexture(tex)
+    assert L.pbrk_mc_region_stats(st, 0) == 0
+    assert st[1] > 0 and st[0] == 0, (int(st[0]), int(st[1]))          # the region kernel ran; nothing had to be recomputed
+    L.GPU_DestroyGraph(g); L.GPU_DestroyDescriptorArena(arena); L.PBR_DestroyIBLPipelines(pipes)
+
+
 def _ibl_maps(L, pbrhip, env64):
     env_tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, 64, 64, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env64)
     maps = pbrhip.PBR_IBLMaps()

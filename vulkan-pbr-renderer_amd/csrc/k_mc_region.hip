@@ -632,32 +632,22 @@ bool launch_mc_region(McArgs a, int nfaces, hipStream_t st) {
             return true;
         }
     }
-    const bool split = false;
-    for (int part = 0; part < 2; ++part) {
-        int f0 = a.face0, f1 = a.face0 + nfaces;
-        if (split) { if (part == 0) f1 = f1 < 2 ? f1 : 2; else f0 = f0 > 2 ? f0 : 2; }
-        else if (part == 1) break;
-        if (f0 >= f1) continue;
-        int tile = (split && part == 0) ? 8 : 16;
-        if (tile_override == 8 || tile_override == 16) tile = tile_override;
-        const int nslices = 1024 / (tile * tile);
-        for (int s = 0; s < REG_MAX_S; ++s) q.expect[s] = 0;
-        for (int w = 0; w < q.NW; ++w) { int c = a.n_tab - w * 32; q.expect[w % nslices] += c > 32 ? 32 : c; }
-        q.a.face0 = f0;
-        q.a.tiles_x = (a.size + tile - 1) / tile;
-        int tiles_y = (a.rows + tile - 1) / tile;
-        q.a.tiles_per_face = q.a.tiles_x * tiles_y;
-        unsigned grid = (unsigned)(q.a.tiles_per_face * (f1 - f0));
-        if (tile == 8) {
-            if (RS == 34) launch_region_t<34, false, 8>(q, grid, lds, st);
-            else if (q.G == 1) launch_region_t<66, false, 8>(q, grid, lds, st);
-            else launch_region_t<66, true, 8>(q, grid, lds, st);
-        } else {
-            if (RS == 18) launch_region_t<18, false, 16>(q, grid, lds, st);
-            else if (RS == 34) launch_region_t<34, false, 16>(q, grid, lds, st);
-            else if (q.G == 1) launch_region_t<66, false, 16>(q, grid, lds, st);
-            else launch_region_t<66, true, 16>(q, grid, lds, st);
-        }
+    const int tile = tile_override == 8 ? 8 : 16;
+    const int nslices = 1024 / (tile * tile);
+    for (int s = 0; s < REG_MAX_S; ++s) q.expect[s] = 0;
+    for (int w = 0; w < q.NW; ++w) { int c = a.n_tab - w * 32; q.expect[w % nslices] += c > 32 ? 32 : c; }
+    q.a.tiles_x = (a.size + tile - 1) / tile;
+    q.a.tiles_per_face = q.a.tiles_x * ((a.rows + tile - 1) / tile);       // tiles start at the dispatch's first row, whatever it is
+    const unsigned grid = (unsigned)(q.a.tiles_per_face * nfaces);
+    if (tile == 8) {
+        if (RS == 34) launch_region_t<34, false, 8>(q, grid, lds, st);
+        else if (q.G == 1) launch_region_t<66, false, 8>(q, grid, lds, st);
+        else launch_region_t<66, true, 8>(q, grid, lds, st);
+    } else {
+        if (RS == 18) launch_region_t<18, false, 16>(q, grid, lds, st);
+        else if (RS == 34) launch_region_t<34, false, 16>(q, grid, lds, st);
+        else if (q.G == 1) launch_region_t<66, false, 16>(q, grid, lds, st);
+        else launch_region_t<66, true, 16>(q, grid, lds, st);
     }
     return true;
 }
