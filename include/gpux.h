@@ -80,4 +80,12 @@ GPU_API float GPUX_GraphTimedOpMs(GPU_Graph* graph, uint32_t index);
  * a negative count restores the default (environment PBR_TILE_STREAMS, else 4).  Results do not depend on the setting. ---- */
 GPU_API void GPUX_SetTileStreams(int count);
 
+/* ---- hipGraph replay of the per-frame chain: with replay on, GPU_GraphSubmit captures the launches of a graph whose ops are all
+ * launch-only (light-grid sweep, draws of the shade / TAA / bloom / tone-map pipelines, blits, memset clears, mip generation) and
+ * whose sampler twins already exist into a hipGraph, updates the executable graph kept from this GPU_Graph's previous submission
+ * in place (same chain, new arguments) and launches it: one dispatch of ~25 dependent kernels instead of 25.  Every other graph, and
+ * every submission while per-op timing is on, runs as before.  Results are identical.  enable < 0: environment PBR_GRAPH_REPLAY, else off. ---- */
+GPU_API void GPUX_SetGraphReplay(int enable);
+GPU_API void GPUX_GraphReplayStats(GPU_Graph* graph, uint64_t* launches, uint64_t* updates, uint64_t* instantiations);
+
 #endif

@@ -320,3 +320,84 @@ def test_gpu_post_wide_frames(gpu, W):
     want8 = O.unorm8(O.final_post_process(up[0]))
     assert np.abs(bb.astype(np.int32) - want8.astype(np.int32)).max() <= 1
     L.PBR_DestroyPostProcess(pp); L.PBR_DestroyGBuffer(C.byref(gb))
+
+
+@pytest.mark.gpu
+def test_gpu_frame_chain_hipgraph_replay_is_identical(gpu):
+    """GPUX_SetGraphReplay: the per-frame chain (light-grid sweep, shade, TAA resolve, bloom, tone map; two graphs in flight as in
+    main.cpp:49-51, 91-99, camera and ping-pong targets changing every frame) submitted through a captured / updated hipGraph
+    produces the same backbuffer, bit for bit, as plain stream launches; the first frames (twins still to be built) and a graph
+    with a host copy in it take the plain path by themselves."""
+    import pbrhip
+    from pbrhip import synth
+    L = gpu
+    L.GPUX_EnableOpTiming(0)                                       # per-op timing keeps a graph on the plain path
+    W, H = 320, 180
+    gbd = synth.synth_gbuffer_spheres(W, H)
+    lighting, depth, vel, vel_prev, history = synth.synth_post_inputs(0x5EED00D1, W, H)
+    env = synth.synth_env(64, seed=0x5EED00AA)
+    env_tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, 64, 64, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+    maps = pbrhip.PBR_IBLMaps()
+    L.PBR_MakeIBLMaps(C.byref(maps), 16, 64, 64)
+    L.PBR_GenIrradianceMap(env_tex, maps.irradiance_map); L.PBR_GenPrefilteredEnvMap(env_tex, maps.tex_specular_env_map, 1); L.PBR_GenBRDFIntegrationMap(maps.brdf_lut)
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), W, H, pbrhip.Format_RGBA16F)
+    for nm, key in (("base_color", "base"), ("normal", "normal"), ("orm", "orm"), ("emissive", "emissive"), ("depth", "depth")):
+        pbrhip.upload_mip(getattr(gb, nm), 0, gbd[key])
+    lp = L.PBR_MakeLightingPass(C.byref(gb), C.byref(maps), W, H)
+    pp = L.PBR_MakePostProcess(C.byref(gb), W, H, pbrhip.Format_BGRA8UN)
+    pbrhip.upload_mip(L.PBR_PostVelocity(pp, 0), 0, vel); pbrhip.upload_mip(L.PBR_PostVelocity(pp, 1), 0, vel_prev)
+    lg = L.PBR_MakeLightgrid(128)
+    scene = synth.synth_lightgrid(128, lit=False).view(np.uint16)
+    graphs = [L.GPU_MakeGraph(), L.GPU_MakeGraph()]
+    frames = 9
+
+    def run(replay):
+        L.GPUX_SetGraphReplay(replay)
+        pbrhip.upload_mip(L.PBR_PostTaaOutput(pp, 1), 0, history)
+        pbrhip.upload_mip(L.PBR_LightgridTexture(lg), 0, scene)
+        outs = []
+        for f in range(frames):
+            g = graphs[f % 2]
+            if f >= 2:
+                L.GPU_GraphWait(g)
+            cam = (float(gbd["cam_pos"][0]) + 0.01 * f, float(gbd["cam_pos"][1]), float(gbd["cam_pos"][2]))
+            glob = pbrhip.fill_globals(cam, aspect=W / H, frame_idx=f % 59)
+            L.PBR_RecordLightgridSweepLines(lg, g, f % 3, 0, 128, 0, 128)
+            L.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
+            L.PBR_RecordTaaResolve(pp, g, f); L.PBR_RecordBloom(pp, g, f); L.PBR_RecordFinalPostProcessBloom(pp, g, f)
+            L.GPU_GraphSubmit(g)
+            if f in (4, frames - 1):
+                L.GPU_GraphWait(graphs[(f + 1) % 2])
+                L.GPU_GraphWait(g)
+                outs.append(pbrhip.read_mip(L.PBR_PostBackbuffer(pp), 0).copy())
+        for g in graphs:
+            L.GPU_GraphWait(g)
+        return outs
+
+    st0 = [C.c_uint64() for _ in range(3)]
+    plain = run(0)
+    L.GPUX_GraphReplayStats(graphs[0], C.byref(st0[0]), C.byref(st0[1]), C.byref(st0[2]))
+    assert st0[0].value == 0
+    replayed = run(1)
+    st = [C.c_uint64() for _ in range(3)]
+    L.GPUX_GraphReplayStats(graphs[0], C.byref(st[0]), C.byref(st[1]), C.byref(st[2]))
+    L.GPUX_SetGraphReplay(0)
+    assert len(plain) == len(replayed) == 2 and float(plain[1].max()) > 0
+    for a, b in zip(plain, replayed):
+        assert np.array_equal(a, b)
+    # graph 0 carried frames 0, 2, 4, 6, 8: all through the captured path (the twins exist since the plain run), one instantiation,
+    # the others in-place updates of the same executable graph
+    assert st[0].value == 5 and st[2].value == 1 and st[1].value == 4, [x.value for x in st]
+    # a graph with a host-visible copy in it is not captured
+    host = L.GPU_MakeBuffer(16, pbrhip.BufferFlag_CPU, None); dev = L.GPU_MakeBuffer(16, pbrhip.BufferFlag_GPU, None)
+    L.GPUX_SetGraphReplay(1)
+    L.GPU_OpCopyBufferToBuffer(graphs[0], host, dev, 0, 0, 16); L.GPU_GraphSubmit(graphs[0]); L.GPU_GraphWait(graphs[0])
+    L.GPUX_SetGraphReplay(0)
+    L.GPUX_GraphReplayStats(graphs[0], C.byref(st[0]), C.byref(st[1]), C.byref(st[2]))
+    assert st[0].value == 5
+    L.GPU_DestroyBuffer(host); L.GPU_DestroyBuffer(dev)
+    for g in graphs:
+        L.GPU_DestroyGraph(g)
+    L.PBR_DestroyLightgrid(lg); L.PBR_DestroyPostProcess(pp); L.PBR_DestroyLightingPass(lp); L.PBR_DestroyGBuffer(C.byref(gb))
+    L.PBR_DestroyIBLMaps(C.byref(maps)); L.GPU_DestroyTexture(env_tex)

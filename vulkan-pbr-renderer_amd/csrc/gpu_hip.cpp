@@ -122,6 +122,11 @@ struct GPU_Graph {
     GPU_RenderPass* preparing = nullptr; GPU_RenderPass* in_pass = nullptr;
     std::vector<DrawParams> draw_params;
     int bound_draw = -1;
+    // hipGraph replay (GPUX_SetGraphReplay): the executable graph of the previous submission, updated in place when the
+    // next one has the same shape
+    hipGraphExec_t exec = nullptr;
+    bool replay_broken = false;                    // a capture failed on this graph: it stays on plain launches
+    uint64_t replay_launches = 0, replay_updates = 0, replay_instantiations = 0;
     // timing of the last waited submission
     std::vector<hipEvent_t> ev;
     std::vector<std::string> timed_names;
@@ -147,6 +152,7 @@ static struct {
     GPU_Sampler samplers[6];
     std::map<TableKey, DeviceTable> tables;
     bool timing = false;
+    int replay = -1;                                // GPUX_SetGraphReplay: submissions go through an instantiated hipGraph (-1: PBR_GRAPH_REPLAY or 0)
 } G;
 
 static const char kTokenLut[] = "HIPK1:gen_brdf_integration_map";
@@ -717,6 +723,7 @@ GPU_API void GPU_DestroyGraph(GPU_Graph* g) {
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : g->sync_ev) (void)hipEventDestroy(e);
     if (g->order_ev) (void)hipEventDestroy(g->order_ev);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (G.last_submitted == g) G.last_submitted = nullptr;        // idle by contract (gpu.h:453): nothing left to order against
     (void)hipStreamDestroy(g->stream);
     delete g;
@@ -1503,6 +1510,54 @@ static double dispatch_samples_per_texel(const Op& op) {
     return tab ? (double)tab->count : (double)n;
 }
 
+// ---- hipGraph replay of the per-frame chain --------------------------------------------------------------------------
+// A frame of the reference records ~25 dependent small launches (light-grid sweep, shade, TAA resolve, 12 bloom passes, tone map:
+// render.cpp:1061-1187) into one GPU_Graph and submits it; on a HIP stream each dependent launch costs ~2.7 us of dispatch latency,
+// inside an instantiated hipGraph ~2.0 us (tools/ubench_graph.hip).  With replay on, GPU_GraphSubmit captures the op loop of an
+// eligible graph into a hipGraph, updates the executable graph kept from the previous submission of the same GPU_Graph in place
+// (hipGraphExecUpdate: same topology, new kernel arguments -- the Globals snapshot, the ping-pong targets) or instantiates a new one,
+// and launches that.  Eligible = every op is a launch-only op whose lazily built inputs (aprons, cells twins, tables) already
+// exist: nothing inside a capture may allocate or synchronise.  Anything else -- the precompute with its side streams, the first
+// frame that still builds twins, per-op timing -- takes the plain path.
+static bool op_replayable(const Op& op) {
+    switch (op.kind) {
+    case Op_Dispatch: return op.cpipe->kernel == Kernel_LightgridSweep;
+    case Op_MipGen: return true;
+    case Op_Blit: return true;
+    case Op_CopyB2B: case Op_CopyB2T: case Op_CopyT2B: return false;          // host pointers may be involved: keep them out of captures
+    case Op_Clear: {
+        const TextureImpl* t = op.tex;
+        // only the memset forms (the staged form synchronises)
+        if (t->texel_bytes == 4) return true;
+        if (op.clear_mode != 0) return false;
+        return op.clear[0] == 0 && op.clear[1] == 0 && op.clear[2] == 0 && op.clear[3] == 0;
+    }
+    case Op_Shade: {
+        KernelId k = op.gpipe->kernel;
+        if (k == Kernel_TaaResolve || k == Kernel_FinalPost || k == Kernel_BloomDown || k == Kernel_BloomUp) return true;
+        GPU_DescriptorSet* s = op.set;
+        TextureImpl* pre = named_slot(s, "PREFILTERED_ENV_MAP")->tex;
+        if (!pre->bordered_valid || pre->bordered_from > 0) return false;
+        for (int l = 0; l < (int)pre->base.mip_level_count; ++l) if (((int)pre->base.width >> l) <= 512 && !cells_ready(pre, l)) return false;
+        if (op.gpipe->shade_flags & GPUX_Shade_IBL) {
+            TextureImpl* irr = named_slot(s, "TEX_IRRADIANCE_MAP")->tex;
+            if (!irr->bordered_valid || irr->bordered_from > 0 || !cells_ready(irr, 0)) return false;
+            if (!named_slot(s, "BRDF_INTEGRATION_MAP")->tex->lut_cells_valid) return false;
+        }
+        return named_slot(s, "GLOBALS")->buf->pinned_host;
+    }
+    }
+    return false;
+}
+
+GPU_API void GPUX_SetGraphReplay(int enable) { G.replay = enable < 0 ? -1 : (enable != 0); }
+GPU_API void GPUX_GraphReplayStats(GPU_Graph* g, uint64_t* launches, uint64_t* updates, uint64_t* instantiations) {
+    if (!g) return;
+    if (launches) *launches = g->replay_launches;
+    if (updates) *updates = g->replay_updates;
+    if (instantiations) *instantiations = g->replay_instantiations;
+}
+
 GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
     GPU_REQUIRE_V(g && !g->submitted, "GPU_GraphSubmit: graph is NULL or already submitted");
     GPU_REQUIRE_V(g->in_pass == nullptr && g->preparing == nullptr, "GPU_GraphSubmit: render pass still open");
@@ -1523,6 +1578,10 @@ GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
         HIP_OK(hipStreamWaitEvent(g->stream, prev->order_ev, 0));
     }
     G.last_submitted = g;
+    if (G.replay < 0) { const char* e = getenv("PBR_GRAPH_REPLAY"); G.replay = e ? (atoi(e) != 0) : 0; }
+    bool capture = G.replay == 1 && !G.timing && !g->replay_broken && !g->ops.empty();
+    if (capture) for (const Op& op : g->ops) if (!op_replayable(op)) { capture = false; break; }
+    if (capture && hipStreamBeginCapture(g->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); capture = false; g->replay_broken = true; }
     // Row-ranged precompute dispatches (the work units of a partitioned job) are too small to keep 256 CUs x 8 waves busy one
     // at a time: consecutive ones whose outputs are disjoint and which do not read each other's output go round-robin onto
     // side streams, fenced by a fork event before the first and join events after the last.  Everything else stays in order.
@@ -1579,6 +1638,28 @@ GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
         g->cur = g->stream;
     }
     close_region();
+    if (capture) {
+        hipGraph_t cg = nullptr;
+        bool ok = hipStreamEndCapture(g->stream, &cg) == hipSuccess && cg;
+        if (ok && g->exec) {
+            hipGraphNode_t bad = nullptr; hipGraphExecUpdateResult res;
+            if (hipGraphExecUpdate(g->exec, cg, &bad, &res) == hipSuccess) ++g->replay_updates;
+            else { (void)hipGetLastError(); (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
+        }
+        if (ok && !g->exec) {
+            if (hipGraphInstantiate(&g->exec, cg, nullptr, nullptr, 0) == hipSuccess) ++g->replay_instantiations;
+            else { (void)hipGetLastError(); g->exec = nullptr; ok = false; }
+        }
+        if (ok && hipGraphLaunch(g->exec, g->stream) == hipSuccess) ++g->replay_launches; else ok = false;
+        if (cg) (void)hipGraphDestroy(cg);
+        if (!ok) {
+            // nothing of the captured work has run: take the plain path for this and every later submission of this graph
+            (void)hipGetLastError();
+            g->replay_broken = true;
+            if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
+            for (Op& op : g->ops) exec_op(g, op, ev_used);
+        }
+    }
     g->submitted = true;
 }
 

@@ -186,6 +186,8 @@ PROTOTYPES = {
     "PBR_ExchangeRanges": (C.c_int, [VP, VP, VP, U32, VP, U32]),
     "PBR_UnitByteRange": (C.c_int, [C.POINTER(PBR_IBLMaps), C.POINTER(PBR_WorkUnit), C.POINTER(TexP), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "PBR_GatherUnits": (C.c_int64, [VP, VP, C.c_int, C.c_int, C.c_int, C.POINTER(PBR_IBLMaps), U32, U32]),
+    "GPUX_SetGraphReplay": (None, [C.c_int]),
+    "GPUX_GraphReplayStats": (None, [VP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "PBR_GatherUnitsMasked": (C.c_int64, [VP, VP, C.c_int, C.c_int, C.c_int, C.POINTER(PBR_IBLMaps), U32, U32, U32]),
     "PBR_GatherPlan": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.POINTER(PBR_IBLMaps), U32, U32, U32, VP, U32]),
     "PBR_SelectUnits": (U32, [C.POINTER(PBR_WorkUnit), U32, U32, C.POINTER(PBR_WorkUnit)]),
