@@ -115,6 +115,8 @@ int pbrk_mc_filter(const void* src_bordered_level, const void* src_cells, int n_
 /* self-check of the region kernel (PBR_MC_STATS=1): {wave-slices whose sample count came up short and were recomputed with
  * direct loads, all wave-slices}; the first must stay 0.  reset != 0 clears the counters after reading. */
 int pbrk_mc_region_stats(unsigned long long* out2, int reset);
+/* the binning's yield with the same switch: {(region, sample) flags set, samples x tiles, regions visited} summed over all tiles since the last reset */
+int pbrk_mc_region_flag_stats(unsigned long long* out3);
 
 /* ---- K5: deferred shade pass (shaders/lighting_pass.glsl:432-716, in-scope sub-blocks). */
 typedef struct PbrkShadeArgs {

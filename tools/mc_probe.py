@@ -57,6 +57,10 @@ def main():
           f"{65 * evals / ms * 1e-9:.1f} TFLOP/s alg  checksum {chk:.6e}", flush=True)
     if os.environ.get("PBR_MC_STATS") == "1":
         st = (C.c_uint64 * 2)()
+        fl = (C.c_uint64 * 3)()
+        if L.pbrk_mc_region_flag_stats(fl) == 0 and fl[1]:
+            tiles = fl[1] // n_tab
+            print(f"   binning: {fl[0] / fl[1]:.3f} regions flagged per sample, {fl[2] / tiles:.2f} regions visited per tile ({tiles} tile launches)", flush=True)
         if L.pbrk_mc_region_stats(st, 1) == 0:
             print(f"   region kernel: {st[0]} of {st[1]} wave-slices recomputed with direct loads", flush=True)
     L.GPU_WaitUntilIdle(); L.GPU_Deinit()

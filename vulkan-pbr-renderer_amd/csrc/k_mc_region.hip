@@ -47,7 +47,8 @@ struct RegArgs {
     int NW;                     // mask words per region = ceil(n_tab / 32)
     int expect[REG_MAX_S];      // samples per slice
     int tile_y0;                // MFMA variant: first tile row (multiple of 16) covering a.y0
-    unsigned long long* stats;  // optional: [0] += healed wave-slices, [1] += all wave-slices
+    int pole_row[2];            // faces +X / -X: tile row (relative to the dispatch's first row, clamped) nearest to the pole of the tangent frame
+    unsigned long long* stats;  // optional: [0] += healed wave-slices, [1] += all wave-slices, [2] += (region, sample) flags, [3] += samples per tile, [4] += regions visited
 };
 
 // direction -> (sc, tc, ma) of face f: the table of v_cubesc / v_cubetc / v_cubema (gen_prefiltered_env_map.glsl:12-23)
@@ -227,7 +228,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     unsigned tile = blockIdx.x;
     const int face = p.face0 + (int)(tile / (unsigned)p.tiles_per_face);
     const int tf = (int)(tile % (unsigned)p.tiles_per_face);
-    const int ty = tf / p.tiles_x, tx = tf % p.tiles_x;
+    int ty = tf / p.tiles_x;
+    const int tx = tf % p.tiles_x;
+    // Longest tiles first: around the pole of the tangent frame (tangent_of: inside the +X face, its antipode inside -X) the frames
+    // of a tile twist against each other, a sample lands in several regions and a tile takes up to 3x as long.  In row order those
+    // tiles came last on the -X face (pole at 3/4 of its height) and the launch ended in their tail; here the rows of these two
+    // faces are dealt outwards from the pole row, so the long tiles start first and the short ones fill in behind them.
+    if (face < 2) {
+        const int ny = p.tiles_per_face / p.tiles_x, pr = q.pole_row[face];
+        const int a = min(pr, ny - 1 - pr);
+        if (ty <= 2 * a) { const int h = (ty + 1) >> 1; ty = (ty & 1) ? pr + h : pr - h; }
+        else { const int rest = ty - 2 * a; ty = (pr > ny - 1 - pr) ? pr - a - rest : pr + a + rest; }
+    }
     // a wave covers an 8 x 8 quadrant of the tile (not 16 x 4): the smaller its extent, the fewer samples its lanes spread over
     // two regions (PBR_MC_WAVE_SHAPE experiment: see DESIGN.md)
     const int q8 = t >> 6, l8 = t & 63;
@@ -257,6 +269,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     // ---- 2. region passes ----
     float ar = 0.0f, ag = 0.0f, ab = 0.0f;
     unsigned cnt = 0;
+    if (q.stats) {                                                 // diagnostics: (region, sample) flags of this tile, samples, regions visited
+        __syncthreads();
+        unsigned fl = 0;
+        for (int k = tid; k < NR * NW; k += 1024) fl += __popc(masks[k]);
+        if (fl) atomicAdd(&q.stats[2], (unsigned long long)fl);
+        if (tid == 0) { atomicAdd(&q.stats[3], (unsigned long long)p.n_tab); unsigned v = 0; for (int r = 0; r < NR; ++r) v += any[r] != 0u; atomicAdd(&q.stats[4], (unsigned long long)v); }
+    }
     for (int r = 0; r < NR; ++r) {
         __syncthreads();                                           // binning done / readers of the previous region done
         if (any[r] == 0u) continue;                                // workgroup-uniform
@@ -568,8 +587,12 @@ static unsigned long long* g_reg_stats = nullptr;      // device counters, enabl
 extern "C" int pbrk_mc_region_stats(unsigned long long* out2, int reset) {
     if (!g_reg_stats || !out2) return PBRK_E_ARG;
     if (hipMemcpy(out2, g_reg_stats, 16, hipMemcpyDeviceToHost) != hipSuccess) return PBRK_E_LAUNCH;
-    if (reset && hipMemset(g_reg_stats, 0, 16) != hipSuccess) return PBRK_E_LAUNCH;
+    if (reset && hipMemset(g_reg_stats, 0, 64) != hipSuccess) return PBRK_E_LAUNCH;
     return PBRK_OK;
+}
+extern "C" int pbrk_mc_region_flag_stats(unsigned long long* out3) {
+    if (!g_reg_stats || !out3) return PBRK_E_ARG;
+    return hipMemcpy(out3, g_reg_stats + 2, 24, hipMemcpyDeviceToHost) == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
 
 template <int RS, bool SUB, int TILE>
@@ -608,7 +631,7 @@ bool launch_mc_region(McArgs a, int nfaces, hipStream_t st) {
     if (tile_override < 0) { const char* e = getenv("PBR_MC_TILE"); tile_override = e ? atoi(e) : 0; }
     if (stats_on < 0) {
         const char* e = getenv("PBR_MC_STATS"); stats_on = e ? atoi(e) : 0;
-        if (stats_on) { if (hipMalloc(&g_reg_stats, 16) != hipSuccess) g_reg_stats = nullptr; else (void)hipMemset(g_reg_stats, 0, 16); }
+        if (stats_on) { if (hipMalloc(&g_reg_stats, 64) != hipSuccess) g_reg_stats = nullptr; else (void)hipMemset(g_reg_stats, 0, 64); }
     }
     q.stats = g_reg_stats;
     // Tile size: 16 x 16 everywhere.  8 x 8 tiles (PBR_MC_TILE=8, an experiment kept for the record) halve the frame spread the
@@ -637,7 +660,17 @@ bool launch_mc_region(McArgs a, int nfaces, hipStream_t st) {
     for (int s = 0; s < REG_MAX_S; ++s) q.expect[s] = 0;
     for (int w = 0; w < q.NW; ++w) { int c = a.n_tab - w * 32; q.expect[w % nslices] += c > 32 ? 32 : c; }
     q.a.tiles_x = (a.size + tile - 1) / tile;
-    q.a.tiles_per_face = q.a.tiles_x * ((a.rows + tile - 1) / tile);       // tiles start at the dispatch's first row, whatever it is
+    const int tiles_y = (a.rows + tile - 1) / tile;
+    q.a.tiles_per_face = q.a.tiles_x * tiles_y;                            // tiles start at the dispatch's first row, whatever it is
+    {   // output row of the tangent frame's pole on faces +X (t = (1 - vy/vx)/2) and -X (t = (1 + vy/vx)/2), v = the vector of tangent_of
+        const double vy_vx = 6.11831989512 / 12.123825810901;
+        for (int f = 0; f < 2; ++f) {
+            int row = (int)((f == 0 ? 0.5 * (1.0 - vy_vx) : 0.5 * (1.0 + vy_vx)) * a.size);
+            int tr = (row - a.y0) / tile;
+            if (row < a.y0) tr = 0;
+            q.pole_row[f] = tr < 0 ? 0 : (tr > tiles_y - 1 ? tiles_y - 1 : tr);
+        }
+    }
     const unsigned grid = (unsigned)(q.a.tiles_per_face * nfaces);
     if (tile == 8) {
         if (RS == 34) launch_region_t<34, false, 8>(q, grid, lds, st);

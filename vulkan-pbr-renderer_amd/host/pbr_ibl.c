@@ -206,12 +206,12 @@ static double time_weight(const PBR_WorkUnit* u) {
 
 /* Faces 0 and 1 (+-X) contain the pole of the tangent frame (`some_vector`): neighbouring texels there take their samples at
  * different azimuths, so the lanes of a wave spread one sample over several regions of the source level and the tile's region
- * flags are wider.  Run alone, single-face dispatches of the region kernel take 1.09x, 1.07x, 1.7x as long there for mips 1-3
- * (tools/face_time.py, C4; with tiles dealt round-robin over the XCDs -- an XCD-contiguous tile order had 1.23x / 1.23x / 1.9x
- * because the slow tiles around the pole all sat on one XCD); the weights below balance the shares of a 4- and 8-way split
- * (tools/rank_time.py). */
+ * flags are wider.  Run alone, single-face dispatches of the region kernel take 1.06x, 1.06x, 1.25x as long there for mips 1-3
+ * (tools/face_flags.sh, C4 shapes; tiles dealt round-robin over the XCDs and, on these two faces, outwards from the pole row so that
+ * the long tiles start first -- in row order with an XCD-contiguous remap it was 1.23x / 1.23x / 1.9x); the weights below balance
+ * the shares of a 4- and 8-way split (tools/rank_time.py). */
 static double face_weight(const PBR_WorkUnit* u, uint32_t face) {
-    static const double pole[6] = {1.0, 1.06, 1.06, 1.3, 1.1, 1.05};
+    static const double pole[6] = {1.0, 1.06, 1.06, 1.25, 1.1, 1.05};
     if (u->kind != PBR_Unit_Prefilter || face > 1 || u->mip > 5) return 1.0;
     return pole[u->mip];
 }

@@ -229,6 +229,7 @@ PROTOTYPES = {
     "pbrk_cells_bytes": (C.c_size_t, [C.c_int]), "pbrk_cells_build": (C.c_int, [VP, C.c_int, VP, VP]),
     "pbrk_shade": (C.c_int, [C.POINTER(PbrkShadeArgs), VP]),
     "pbrk_mc_region_stats": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
+    "pbrk_mc_region_flag_stats": (C.c_int, [C.POINTER(C.c_uint64)]),
     "pbrk_lut_cells_build": (C.c_int, [VP, C.c_int, VP, VP]),
     "pbrk_equirect_to_cube": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, VP]),
 }
