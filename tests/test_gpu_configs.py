@@ -188,3 +188,58 @@ def test_c5_shade_temple(gpu, c5_gbuffer):
     screen split), bit for bit; rows through the dome, the column ring and the ground equal the oracle to 1e-4.  The synthetic
     temple is closed by its dome: it has no sky pixels (the sky branch is covered at C3)."""
     _shade_full_size(gpu, c5_gbuffer, 8, (300, 2200, 4100), expect_sky=False)
+
+
+_VARIANT_CHILD = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(sys.argv[1], "vulkan-pbr-renderer_amd", "python"))
+from pbrhip import synth
+envs = {W: synth.synth_env(W, seed=0x5EED00AE + W) for W in (256, 1024)}
+import pbrhip
+L = pbrhip.init(0)
+out = {}
+for W, S in ((256, 512), (1024, 1024)):
+    tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, W, W, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, envs[W])
+    spec = pbrhip.make_texture(pbrhip.Format_RGBA32F, S, S, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps | pbrhip.TextureFlag_StorageImage)
+    L.PBR_GenPrefilteredEnvMap(tex, spec, 256)
+    for m in range(1, 3):
+        if (S >> m) >= 256:
+            out[f"{W}_{S}_{m}"] = pbrhip.read_mip(spec, m)[:, ::37].copy()          # every 37th row of every face
+    L.GPU_DestroyTexture(spec); L.GPU_DestroyTexture(tex)
+st = (C.c_uint64 * 2)()
+rc = L.pbrk_mc_region_stats(st, 0)
+out["stats"] = np.array([rc, st[0], st[1]], np.int64)
+np.savez(sys.argv[2], **out)
+L.GPU_WaitUntilIdle(); L.GPU_Deinit()
+"""
+
+
+def test_region_kernel_recorded_variants_agree(gpu, tmp_path):
+    """The variant of K4b's region kernel that is kept as the record of a measured dead end -- the fp32-MFMA frame transform
+    (PBR_MC_MFMA=1) -- and the level-in-LDS / direct kernels that served these levels before (PBR_MC_REGION=0) still
+    compute the same maps as the shipped kernel (same taps and weights; only the order of the additions differs: <= 1e-5
+    relative), the region variants with no wave recomputed.  The switches are read once per process: every variant runs in a child."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "variant_child.py"
+    script.write_text(_VARIANT_CHILD)
+    res = {}
+    for name, env in (("default", {}), ("mfma", {"PBR_MC_MFMA": "1"}), ("noregion", {"PBR_MC_REGION": "0"})):
+        out = tmp_path / f"{name}.npz"
+        e = dict(os.environ, PBR_MC_STATS="1", **env)
+        r = subprocess.run([sys.executable, str(script), root, str(out)], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        z = np.load(out)
+        res[name] = {k: z[k] for k in z.files}
+        rc, healed, total = (int(v) for v in res[name]["stats"])
+        if name != "noregion":
+            assert rc == 0 and total > 0 and healed == 0, (name, rc, healed, total)
+    keys = [k for k in res["default"] if k != "stats"]
+    assert len(keys) == 3
+    for name in ("mfma", "noregion"):
+        for k in keys:
+            a, b = res["default"][k].astype(np.float64), res[name][k].astype(np.float64)
+            assert float(np.abs(a[..., :3]).max()) > 0
+            err = float((np.abs(a - b)[..., :3] / np.maximum(np.abs(a[..., :3]), 1e-3)).max())
+            assert err < 1e-5, (name, k, err)

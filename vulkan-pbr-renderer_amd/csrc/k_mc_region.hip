@@ -34,7 +34,7 @@ typedef const __attribute__((address_space(4))) v4f* ctab_t;
 typedef const __attribute__((address_space(3))) v4f* lds_v4f_p;
 
 // A 1024-thread workgroup owns a TILE x TILE block of output texels and 1024 / TILE^2 slices of the sample table:
-//   TILE 16: 256 texels x 4 slices (waves 4s .. 4s+3 own slice s);   TILE 8: 64 texels x 16 slices (one wave per slice).
+//   TILE 16 (the only instantiation): 256 texels x 4 slices (waves 4s .. 4s+3 own slice s).
 // The smaller tile halves the frame spread delta the region flags are built from (fewer samples flagged for two regions) and
 // pays four times the binning / staging per texel: it wins where regions are small next to that spread (n_src <= 32).
 #define REG_MAX_S 16
@@ -627,17 +627,14 @@ bool launch_mc_region(McArgs a, int nfaces, hipStream_t st) {
     size_t lds = (size_t)RS * RS * 16 + ((size_t)q.NR * q.NW + q.NR + 4) * 4;
     if (lds < (size_t)1024 * 3 * 4) lds = (size_t)1024 * 3 * 4;      // the slices' partial sums (REG_S * REG_TX = 1024 texel-slices)
     if (lds > 80 * 1024) return false;                             // two workgroups per CU or not at all
-    static int tile_override = -1;
-    if (tile_override < 0) { const char* e = getenv("PBR_MC_TILE"); tile_override = e ? atoi(e) : 0; }
     if (stats_on < 0) {
         const char* e = getenv("PBR_MC_STATS"); stats_on = e ? atoi(e) : 0;
         if (stats_on) { if (hipMalloc(&g_reg_stats, 64) != hipSuccess) g_reg_stats = nullptr; else (void)hipMemset(g_reg_stats, 0, 64); }
     }
     q.stats = g_reg_stats;
-    // Tile size: 16 x 16 everywhere.  8 x 8 tiles (PBR_MC_TILE=8, an experiment kept for the record) halve the frame spread the
-    // region flags are built from but pay four times the per-tile work (binning, staging, prologue): C4 mip 2 44.0 -> 53.5 ms,
-    // mip 3 12.0 -> 13.6 ms, mip 1 37.0 -> 54.5 ms; even restricted to the faces that hold the pole of the tangent frame (+-X: a
-    // single-face dispatch of mip 3 runs 4.1 -> 3.0 ms) the second launch costs more than it saves (12.0 -> 12.8 ms per level).
+    // Tile size: 16 x 16 output texels x 4 slices of the sample table everywhere.  Measured and dropped: 8 x 8 tiles x 16
+    // slices (halve the frame spread, pay four times the per-tile work: C4 mip 2 44.0 -> 53.5 ms), 32 x 16 and 32 x 32 tiles (no gain
+    // on the big levels, losses on the small ones).
     static int mfma_mode = -1;
     if (mfma_mode < 0) { const char* e = getenv("PBR_MC_MFMA"); mfma_mode = e ? atoi(e) : 0; }      // opt-in: measured slower (see above)
     if (mfma_mode && q.NW <= 256) {
@@ -655,8 +652,7 @@ bool launch_mc_region(McArgs a, int nfaces, hipStream_t st) {
             return true;
         }
     }
-    const int tile = tile_override == 8 ? 8 : 16;
-    const int nslices = 1024 / (tile * tile);
+    const int tile = 16, nslices = 4;
     for (int s = 0; s < REG_MAX_S; ++s) q.expect[s] = 0;
     for (int w = 0; w < q.NW; ++w) { int c = a.n_tab - w * 32; q.expect[w % nslices] += c > 32 ? 32 : c; }
     q.a.tiles_x = (a.size + tile - 1) / tile;
@@ -672,15 +668,9 @@ bool launch_mc_region(McArgs a, int nfaces, hipStream_t st) {
         }
     }
     const unsigned grid = (unsigned)(q.a.tiles_per_face * nfaces);
-    if (tile == 8) {
-        if (RS == 34) launch_region_t<34, false, 8>(q, grid, lds, st);
-        else if (q.G == 1) launch_region_t<66, false, 8>(q, grid, lds, st);
-        else launch_region_t<66, true, 8>(q, grid, lds, st);
-    } else {
-        if (RS == 18) launch_region_t<18, false, 16>(q, grid, lds, st);
-        else if (RS == 34) launch_region_t<34, false, 16>(q, grid, lds, st);
-        else if (q.G == 1) launch_region_t<66, false, 16>(q, grid, lds, st);
-        else launch_region_t<66, true, 16>(q, grid, lds, st);
-    }
+    if (RS == 18) launch_region_t<18, false, 16>(q, grid, lds, st);
+    else if (RS == 34) launch_region_t<34, false, 16>(q, grid, lds, st);
+    else if (q.G == 1) launch_region_t<66, false, 16>(q, grid, lds, st);
+    else launch_region_t<66, true, 16>(q, grid, lds, st);
     return true;
 }
