@@ -253,14 +253,14 @@ __global__ __launch_bounds__(256) void k_cells_build(const float4* __restrict__ 
     if (i >= nc || j >= nc) return;
     const float4* p = b + ((size_t)f * nb + j) * nb + i;
     float4 t00 = p[0], t10 = p[1], t01 = p[nb], t11 = p[nb + 1];
-    float4* o = cells + ((size_t)(f * nc + j) * nc + i) * 3;
+    float4* o = cells + ((size_t)(f * nc + j) * nc + i) * PBR_CELL_F4;
     // coefficient form {t00, t10 - t00, t01, t11 - t01}: the differences are the (rounded) ones lerp_fma would form per fetch
     o[0] = make_float4(t00.x, t00.y, t00.z, t10.x - t00.x);
     o[1] = make_float4(t10.y - t00.y, t10.z - t00.z, t01.x, t01.y);
     o[2] = make_float4(t01.z, t11.x - t01.x, t11.y - t01.y, t11.z - t01.z);
 }
 
-extern "C" size_t pbrk_cells_bytes(int n) { return (size_t)6 * (n + 1) * (n + 1) * 48; }
+extern "C" size_t pbrk_cells_bytes(int n) { return (size_t)6 * (n + 1) * (n + 1) * PBR_CELL_BYTES; }
 
 extern "C" int pbrk_cells_build(const void* bordered_level, int n, void* cells, void* stream) {
     if (!bordered_level || !cells || n < 1) return PBRK_E_ARG;

@@ -49,7 +49,7 @@ __device__ __forceinline__ f3 sample_bordered(__amdgpu_buffer_rsrc_t rs, f3 L, f
         // integer multiplies (v_mul_lo_u32 / v_mad_u64_u32 issue at 1.45x / 1.7x the cost of an FMA here, tools/ubench_valu.hip).
         float ncf = (float)(nb - 1);                             // n + 1 tap positions per edge
         float cellf = fmaf(fmaf(fid, ncf, floorf(v)), ncf, floorf(u));
-        return fetch_cells(rs, (int)(cellf * 48.0f), a, b);
+        return fetch_cells(rs, (int)(cellf * (float)PBR_CELL_BYTES), a, b);
     }
     int i0 = (int)u, j0 = (int)v, face = (int)fid;
     int voff = ((face * nb + j0) * nb + i0) << 4;

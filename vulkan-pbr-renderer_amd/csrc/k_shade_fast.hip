@@ -28,7 +28,7 @@ __device__ __forceinline__ f3 pre_level_fetch(__amdgpu_buffer_rsrc_t rc, float f
     float a = u - fu, b = v - fv;
     float ncf = nf + 1.0f;
     float cellf = fmaf(fmaf(fid, ncf, fv + 1.0f), ncf, fu + 1.0f);  // (face * nc + j0) * nc + i0, bordered tap coordinates, exact in fp32
-    int off = (int)(cellf * 48.0f) + level_bytes;
+    int off = (int)(cellf * (float)PBR_CELL_BYTES) + level_bytes;
     return cells_bilerp(bl4(rc, off), bl4(rc, off + 16), bl4(rc, off + 32), a, b);
 }
 
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         float u = fmaf(sc, h, off1), v = fmaf(tc, h, off1);
         float a = __builtin_amdgcn_fractf(u), b = __builtin_amdgcn_fractf(v);
         float ncf = nf + 1.0f;
-        int off = (int)(fmaf(fmaf(fid, ncf, v - b), ncf, u - a) * 48.0f);       // (face * nc + j0) * nc + i0, exact in fp32
-        __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)p.irr_cells, 0, 6 * (p.irr_size + 1) * (p.irr_size + 1) * 48, 0x00020000);
+        int off = (int)(fmaf(fmaf(fid, ncf, v - b), ncf, u - a) * (float)PBR_CELL_BYTES);       // (face * nc + j0) * nc + i0, exact in fp32
+        __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)p.irr_cells, 0, 6 * (p.irr_size + 1) * (p.irr_size + 1) * PBR_CELL_BYTES, 0x00020000);
         amb = cells_bilerp(bl4(ri, off), bl4(ri, off + 16), bl4(ri, off + 32), a, b);
     }
 

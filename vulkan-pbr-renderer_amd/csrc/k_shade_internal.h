@@ -42,7 +42,7 @@ __device__ __forceinline__ void mat_mul(const float* m, float x, float y, float 
 }
 __device__ __forceinline__ int cells_level_off(int W, int first, int level) {
     int off = 0;
-    for (int l = first; l < level; ++l) { int n = max(W >> l, 1) + 1; off += 6 * n * n * 3; }
+    for (int l = first; l < level; ++l) { int n = max(W >> l, 1) + 1; off += 6 * n * n * PBR_CELL_F4; }
     return off;
 }
 

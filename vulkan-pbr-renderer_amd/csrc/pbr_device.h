@@ -183,6 +183,13 @@ __device__ __forceinline__ f3 fetch_rgb_tap(const float4* __restrict__ lvl, int 
     r.z = lerp_fma(lerp_fma(t00.z, t10.z, t.a), lerp_fma(t01.z, t11.z, t.a), t.b);
     return r;
 }
+// Stride of a cell in float4 units: 3 = packed (48 B).  4 (one 64-byte sector per cell, the fourth float4 padding, so that a
+// scattered cell fetch never straddles two sectors) was measured on K5's prefiltered taps and is slower: 567 vs 540 us on the 8K
+// frame -- a third more bytes through the caches outweighs the saved straddles.
+#ifndef PBR_CELL_F4
+#define PBR_CELL_F4 3
+#endif
+#define PBR_CELL_BYTES (16 * PBR_CELL_F4)
 // One cell of the "cells" twin = the 2x2 RGB footprint of a tap position in coefficient form, 48 bytes:
 //   A = (t00.rgb, d0.r)   B = (d0.gb, t01.rg)   C = (t01.b, d1.rgb)      d0 = t10 - t00, d1 = t11 - t01 (rounded once, at build time)
 // fma(a, d0, t00) is lerp_fma(t00, t10, a) bit for bit (lerp_fma forms the same rounded difference), so a bilinear fetch from a
@@ -194,7 +201,7 @@ __device__ __forceinline__ f3 cells_bilerp(float4 A, float4 Bq, float4 Cq, float
 }
 __device__ __forceinline__ f3 fetch_rgb_cells_tap(const float4* __restrict__ cells, int n, const CubeTap& t) {
     int nc = n + 1;
-    const float4* c = cells + (size_t)((t.face * nc + t.j0) * nc + t.i0) * 3;
+    const float4* c = cells + (size_t)((t.face * nc + t.j0) * nc + t.i0) * PBR_CELL_F4;
     return cells_bilerp(c[0], c[1], c[2], t.a, t.b);
 }
 
@@ -233,7 +240,7 @@ template <bool EXACT>
 __device__ __forceinline__ f3 cube_fetch_rgb_cells(const float4* __restrict__ cells, int n, f3 d) {
     CubeTap t = cube_tap<EXACT>(d, n);
     int nc = n + 1;
-    const float4* c = cells + (size_t)((t.face * nc + t.j0) * nc + t.i0) * 3;
+    const float4* c = cells + (size_t)((t.face * nc + t.j0) * nc + t.i0) * PBR_CELL_F4;
     return cells_bilerp(c[0], c[1], c[2], t.a, t.b);
 }
 
