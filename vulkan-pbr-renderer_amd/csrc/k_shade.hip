@@ -290,8 +290,12 @@ template <bool kGI>
 __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
     __shared__ int level_tab[32];
     fill_level_table(level_tab, p.pre_size, min(p.pre_levels, 16), p.pre_cells_first);
-    {   // grid: x = 64-pixel column blocks, y = 4-row blocks (no integer division per pixel)
-        int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6);
+    {   // grid: x = 64-pixel column blocks, y = 4-row blocks (no integer division per pixel).  The GI instantiation takes 8 x 8 pixels
+        // per wave (a 32 x 8 block): its traces diverge, and a square footprint has fewer waves that straddle a surface edge and
+        // rays that stay closer together than a 64 x 1 strip (lane utilisation 0.53 -> see DESIGN.md).
+        int lx, ly;
+        if (kGI) { lx = blockIdx.x * 32 + (threadIdx.x >> 6) * 8 + (threadIdx.x & 7); ly = blockIdx.y * 8 + ((threadIdx.x >> 3) & 7); }
+        else { lx = blockIdx.x * 64 + (threadIdx.x & 63); ly = blockIdx.y * 4 + (threadIdx.x >> 6); }
         if (lx >= p.w || ly >= p.h) return;
         int px = p.x0 + lx, py = p.y0 + ly;
         size_t pi = (size_t)py * p.width + px;
@@ -567,7 +571,7 @@ extern "C" int pbrk_shade(const PbrkShadeArgs* a, void* stream) {
         p.pre_cells_bytes = (int)cb;
         return launch_shade_fast(p, (a->flags & PBRK_SHADE_IBL) != 0, (a->flags & PBRK_SHADE_SHAFTS) != 0, (hipStream_t)stream);
     }
-    if (a->flags & PBRK_SHADE_GI) hipLaunchKernelGGL(k_shade<true>, dim3((p.w + 63) / 64, (p.h + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    if (a->flags & PBRK_SHADE_GI) hipLaunchKernelGGL(k_shade<true>, dim3((p.w + 31) / 32, (p.h + 7) / 8), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(k_shade<false>, dim3((p.w + 63) / 64, (p.h + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
