@@ -14,6 +14,8 @@ from pbrhip import synth  # noqa: E402
 W, H = 1920, 1080
 gbd, grid, levels, sun = synth.synth_gi_scene(W, H)
 import pbrhip  # noqa: E402
+if os.environ.get("PBRHIP_LIB"):
+    pbrhip.LIB_PATH = os.environ["PBRHIP_LIB"]
 
 L = pbrhip.init(0)
 L.GPUX_EnableOpTiming(1)

@@ -196,6 +196,9 @@ __device__ __forceinline__ f3 luminance_normalise(float x, float y, float z) {  
     float k = sqrtf(luminance) / fmaxf(luminance, 0.0001f);
     return mk3(x * k, y * k, z * k);
 }
+#ifndef GI_AHEAD
+#define GI_AHEAD 4
+#endif
 // lighting_pass.glsl:273-424 SampleRadianceWithScreenSpaceTrace
 __device__ __forceinline__ f3 sample_radiance_ss(const ShadeParams& p, f3 V, const float* p0_vs, f3 ray_origin, f3 ray_direction,
                                               int num_steps, float step_scale, float noise_01, float foggyness, float ss_intensity) {
@@ -276,11 +279,25 @@ __device__ __forceinline__ f3 sample_radiance_ss(const ShadeParams& p, f3 V, con
     if (s3 < 0.5f) return mk3(0.0f, 0.0f, 0.0f);                                          // :400-403
     rd = scale3(rd, step_scale);                                                          // :407-408
     ro = mk3(ro.x + rd.x * noise_01, ro.y + rd.y * noise_01, ro.z + rd.z * noise_01);
-    for (int i = 0; i < num_steps; ++i) {                                                 // :411-419
-        ro = mk3(ro.x + 0.5f * rd.x, ro.y + 0.5f * rd.y, ro.z + 0.5f * rd.z);
-        float4 rad = grid_at(p, ro);
-        if (rad.w > 0.3f) break;
-        s0 = s0 * foggyness + rad.x; s1 = s1 * foggyness + rad.y; s2 = s2 * foggyness + rad.z; s3 = s3 * foggyness + 1.0f;
+    // :411-419.  The march positions do not depend on what is read (only the exit does), so the samples of GI_AHEAD steps are
+    // fetched together and consumed in order: the same values in the same order, GI_AHEAD times fewer dependent round trips
+    // (num_steps is 12 or 16).
+    for (int i = 0; i < num_steps; i += GI_AHEAD) {
+        f3 rk[GI_AHEAD]; float4 radk[GI_AHEAD];
+#pragma unroll
+        for (int k = 0; k < GI_AHEAD; ++k) {
+            ro = mk3(ro.x + 0.5f * rd.x, ro.y + 0.5f * rd.y, ro.z + 0.5f * rd.z);
+            rk[k] = ro;
+            radk[k] = grid_at(p, ro);
+        }
+        bool done = false;
+#pragma unroll
+        for (int k = 0; k < GI_AHEAD; ++k) {
+            if (done || i + k >= num_steps) break;
+            if (radk[k].w > 0.3f) { done = true; break; }
+            s0 = s0 * foggyness + radk[k].x; s1 = s1 * foggyness + radk[k].y; s2 = s2 * foggyness + radk[k].z; s3 = s3 * foggyness + 1.0f;
+        }
+        if (done) break;
     }
     return luminance_normalise(s0 / s3, s1 / s3, s2 / s3);                                // :421-423
 }
