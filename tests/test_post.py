@@ -397,6 +397,18 @@ def test_gpu_frame_chain_hipgraph_replay_is_identical(gpu):
     L.GPUX_GraphReplayStats(graphs[0], C.byref(st[0]), C.byref(st[1]), C.byref(st[2]))
     assert st[0].value == 5
     L.GPU_DestroyBuffer(host); L.GPU_DestroyBuffer(dev)
+    # the same GPU_Graph with a different chain (TAA + tone map only): the kept executable graph cannot be updated in place and is
+    # replaced; the frame equals the plain one
+    outs = []
+    for replay in (0, 1):
+        L.GPUX_SetGraphReplay(replay)
+        pbrhip.upload_mip(L.PBR_PostTaaOutput(pp, 1), 0, history)
+        L.PBR_RecordTaaResolve(pp, graphs[0], 0); L.PBR_RecordFinalPostProcess(pp, graphs[0], 0)
+        L.GPU_GraphSubmit(graphs[0]); L.GPU_GraphWait(graphs[0])
+        outs.append(pbrhip.read_mip(L.PBR_PostBackbuffer(pp), 0).copy())
+    L.GPUX_SetGraphReplay(0)
+    L.GPUX_GraphReplayStats(graphs[0], C.byref(st[0]), C.byref(st[1]), C.byref(st[2]))
+    assert np.array_equal(outs[0], outs[1]) and st[0].value == 6 and st[2].value == 2, [x.value for x in st]
     for g in graphs:
         L.GPU_DestroyGraph(g)
     L.PBR_DestroyLightgrid(lg); L.PBR_DestroyPostProcess(pp); L.PBR_DestroyLightingPass(lp); L.PBR_DestroyGBuffer(C.byref(gb))
