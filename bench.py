@@ -440,6 +440,10 @@ def main():
             extra["lightgrid_sweep"] = sweep_bench(L, pbrhip)
         except Exception as e:
             extra["lightgrid_sweep_error"] = repr(e)
+        try:
+            extra["lut_c1"] = lut_bench(L, pbrhip)
+        except Exception as e:
+            extra["lut_c1_error"] = repr(e)
 
     if not args.no_shade and not args.no_c5:                      # every rank takes part (screen bands + gather)
         c5 = shade_c5_bench(L, pbrhip, env_tex, rank, world, backend, torch, dist, c5_gbd, frames=args.c5_frames, comm=comm)
@@ -736,6 +740,31 @@ def post_bench(L, pbrhip, frames=20):
                                "achieved": byt / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": byt / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
     L.GPU_DestroyGraph(g); L.PBR_DestroyPostProcess(pp); L.PBR_DestroyGBuffer(C.byref(gb))
+    return res
+
+
+def lut_bench(L, pbrhip, runs=10):
+    """C1: the 256^2 split-sum BRDF LUT (K1, gen_brdf_integration_map.glsl:142-210; render.cpp:591-619), 4096 samples per texel."""
+    t = pbrhip.make_texture(pbrhip.Format_RG16F, 256, 256, pbrhip.TextureFlag_StorageImage)
+    pipes = L.PBR_MakeIBLPipelines(); arena = L.GPU_MakeDescriptorArena(); g = L.GPU_MakeGraph()
+    maps = pbrhip.PBR_IBLMaps(); maps.brdf_lut = t
+    u = (pbrhip.PBR_WorkUnit * 1)(); u[0].kind = pbrhip.Unit_BrdfLut; u[0].row0 = 0; u[0].row1 = 256; u[0].face0 = 0; u[0].face1 = 1
+    ms = []
+    for _ in range(runs + 1):
+        L.PBR_RecordUnits(pipes, g, arena, None, C.byref(maps), u, 1)
+        L.GPU_GraphSubmit(g); L.GPU_GraphWait(g); L.GPU_ResetDescriptorArena(arena)
+        ms += [L.GPUX_GraphTimedOpMs(g, i) for i in range(L.GPUX_GraphTimedOpCount(g))]
+    k_ms = float(np.median(ms[1:]))
+    evals = 256.0 * 256.0 * 4096.0
+    res = {"workload": "C1: 256x256 split-sum BRDF LUT, 4096 samples per texel, RG16F target", "runs": runs, "kernel_ms": k_ms,
+           "mtexels_per_s": 65536.0 / (k_ms * 1e-3) / 1e6, "msamples_per_s": evals / (k_ms * 1e-3) / 1e6,
+           # executed work per (sample, texel): the row part (6 mul + 2 FMA = 10 flop, one v_exp_f32) + 1/16 of the column part (~60 flop, 3 transcendentals)
+           "roofline": {"kernel": "K1.brdf_lut", "bound": "valu", "achieved": evals * 13.75 / (k_ms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": evals * 13.75 / (k_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                        "shader_equivalent_tflops": evals * 60.0 / (k_ms * 1e-3) / 1e12,
+                        "note": "priced by the work the kernel executes (13.75 flop + 1.2 transcendentals per sample and texel: the roughness-independent part of a "
+                                "sample is evaluated once per column x 16 rows); the shader's own 60 flop per sample (SURVEY 8d) would read shader_equivalent_tflops"}}
+    L.GPU_DestroyGraph(g); L.GPU_DestroyDescriptorArena(arena); L.PBR_DestroyIBLPipelines(pipes); L.GPU_DestroyTexture(t)
     return res
 
 
