@@ -12,6 +12,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vulkan-pbr-renderer_amd", "python"))
 import pbrhip  # noqa: E402
+if os.environ.get("PBRHIP_LIB"):
+    pbrhip.LIB_PATH = os.environ["PBRHIP_LIB"]
 
 
 def main():
