@@ -16,6 +16,8 @@ TW, TH = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2
 scenes = [("spheres 1920x1080", synth.synth_gbuffer_spheres(1920, 1080)),
           (f"temple {TW}x{TH}", synth.synth_gbuffer_temple(TW, TH, workers=int(os.environ.get("PROBE_WORKERS", min(16, os.cpu_count() or 1)))))]   # PROBE_WORKERS=1 under a profiler (no fork)
 import pbrhip  # noqa: E402
+if os.environ.get("PBRHIP_LIB"):
+    pbrhip.LIB_PATH = os.environ["PBRHIP_LIB"]
 import pbr_oracle as O  # noqa: E402
 
 L = pbrhip.init(0)
