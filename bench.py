@@ -2,7 +2,9 @@
 """bench.py -- headline benchmark of the IBL-precompute hot path on MI355X.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c2|ref]
-  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  N > 1: either the launcher form (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+         or plain `python bench.py --gpus N`: without WORLD_SIZE in the environment the script starts its N workers itself
+         (a child `torch.distributed.run`, decided before anything touches the GPU) and exits with their code.
 
 One "step" = one full IBL precompute of the workload with the environment cube's level 0 already
 resident in HBM: mip-chain build (K2) + apron build + specular prefilter of every mip (K4a copy,
@@ -18,6 +20,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -144,16 +148,34 @@ def main():
                     help="record the job as two graphs (mip-1 units first) and send each part while the next computes (PBR_RunPartitionedIBL; "
                          "needs the C gather for N > 1; opt-in: never run on more than one GPU)")
     ap.add_argument("--check", action="store_true", help="after the run, spot-check output texels against the oracle")
+    ap.add_argument("--dry-launch", action="store_true", help="print the worker command `--gpus N` would start and exit 0 (no GPU, no torch)")
     args = ap.parse_args()
+
+    # ---- N > 1 without a launcher: become the launcher.  Decided here, before torch / HIP are touched: the workers are CHILD
+    # processes (never an exec from a process that has initialised the GPU), rank 0 of them prints the one JSON line.
+    if args.dry_launch or (args.gpus > 1 and "WORLD_SIZE" not in os.environ):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        worker_args = [a for a in sys.argv[1:] if a != "--dry-launch"]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + worker_args
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+        if args.dry_launch:
+            print(json.dumps({"dry_launch": True, "n_workers": args.gpus, "cmd": cmd,
+                              "env": {k: env[k] for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS")}}))
+            sys.exit(0)
+        sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree", file=sys.stderr)
+        sys.exit(2)
 
     W, spec_size, irr_size, seed, desc = WORKLOADS[args.workload]
     # inputs first (fork-based workers), GPU afterwards
@@ -201,6 +223,20 @@ def main():
             else:
                 comm = None
                 gather_impl = "torch.distributed (C gather unavailable)"
+    # which RCCL the C host layer bound (it binds at first use: here torch was imported first, so it is torch's bundled copy --
+    # the same copy that made `comm`), and what the communicator itself says about its size
+    rccl_report = None
+    if world > 1:
+        rccl_report = {"backend": backend, "gather": gather_impl, "version": None, "library": None, "comm_ranks": None, "comm_rank_of_rank0": None}
+        try:
+            ver, path = pbrhip.rccl_info()
+            rccl_report.update(version=ver, library=path)
+            if comm is not None:
+                n_c, r_c = pbrhip.comm_info(comm)
+                rccl_report.update(comm_ranks=n_c, comm_rank_of_rank0=r_c)
+                assert n_c == world and r_c == rank, f"communicator reports {r_c}/{n_c}, launcher says {rank}/{world}"
+        except RuntimeError as e:
+            rccl_report["error"] = repr(e)
 
     # ---- resources: env cube (level 0 resident), output maps over torch-owned HBM (so RCCL can move them)
     env_tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, W, W, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
@@ -270,7 +306,9 @@ def main():
             L.GPU_GraphWait(graph2); L.GPU_GraphWait(graph)
             L.GPU_ResetDescriptorArena(arena)
             t_b = time.perf_counter()
-            k_s = sum(L.GPUX_GraphTimedOpMs(g_, i) for g_ in (graph, graph2) for i in range(L.GPUX_GraphTimedOpCount(g_))) * 1e-3
+            # compute = the two graphs' busy spans on their own streams (one event pair each: dispatches overlapping on side
+            # streams are not counted twice); exchange = what the step took beyond that
+            k_s = (L.GPUX_GraphSpanMs(graph) + L.GPUX_GraphSpanMs(graph2)) * 1e-3
             phase["compute"] += min(k_s, t_b - t_a); phase["exchange"] += max(0.0, t_b - t_a - k_s)
             return
         L.PBR_RecordUnits(pipes, graph, arena, env_tex, C.byref(maps), my_units, n_my)
@@ -282,8 +320,8 @@ def main():
         L.GPU_GraphWait(graph)                                                    # ... and this waits for both
         L.GPU_ResetDescriptorArena(arena)
         t_b = time.perf_counter()
-        if comm is not None:                                                      # split by the kernels' own event timings
-            k_s = sum(L.GPUX_GraphTimedOpMs(graph, i) for i in range(L.GPUX_GraphTimedOpCount(graph))) * 1e-3
+        if comm is not None:                                                      # split by the graph's busy span (first op .. last join, one event pair)
+            k_s = L.GPUX_GraphSpanMs(graph) * 1e-3
             phase["compute"] += min(k_s, t_b - t_a); phase["exchange"] += max(0.0, t_b - t_a - k_s)
             return
         phase["compute"] += t_b - t_a
@@ -500,7 +538,7 @@ def main():
             "config": {"workload": desc, "env": f"procedural HDR cube {W}^2 x6 RGBA32F (seed {seed:#x}, RGBE round-tripped)",
                        "texels_per_step": total_texels, "sample_evaluations_per_step": sample_evals,
                        "overlap": overlap, "parallelism": "single GPU" if world == 1 else f"{world} ranks, weighted linear partition of output rows (3-8 dispatches per rank), 1 grouped RCCL send/recv gather per step"},
-            "roofline": roofline, "roofline_hbm": roofline_hbm, "rates": rates, "step_split": step_split, "kernels": kernels[:12],
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "rates": rates, "step_split": step_split, "rccl": rccl_report, "kernels": kernels[:12],
             "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(out))

@@ -73,6 +73,9 @@ GPU_API void GPUX_EnableOpTiming(int enable);
 GPU_API uint32_t GPUX_GraphTimedOpCount(GPU_Graph* graph);          /* ops of the last waited submission */
 GPU_API const char* GPUX_GraphTimedOpName(GPU_Graph* graph, uint32_t index);
 GPU_API float GPUX_GraphTimedOpMs(GPU_Graph* graph, uint32_t index);
+/* busy span of the last waited submission on the graph's main stream: one event pair from before its first op to after the
+ * last join of its side streams (overlapping dispatches are not counted twice, unlike the sum of the per-op times) */
+GPU_API float GPUX_GraphSpanMs(GPU_Graph* graph);
 
 /* ---- overlap of small precompute dispatches: consecutive row-ranged K3/K4 dispatches (GPUX_OpDispatchRows) of fewer than
  * 2M texels whose outputs are disjoint and that do not read each other's output are spread over `count` side streams

@@ -81,7 +81,17 @@ uint32_t PBR_PartitionIBL(uint32_t specular_size, uint32_t min_size, uint32_t ir
  * trip; GPU_GraphWait(graph) then also waits for the exchange.  Negative return values are PBR_E_*. ---- */
 enum { PBR_OK = 0, PBR_E_BADARG = -1, PBR_E_COMM = -2 };
 typedef struct PBR_XferRange { void* ptr; uint64_t bytes; int peer; } PBR_XferRange;    /* device pointer, byte count, peer rank */
-/* ncclGroupStart; ncclRecv x n_recvs; ncclSend x n_sends; ncclGroupEnd (a rank may send to itself) */
+/* RCCL is bound at first use (dlopen), never at link time: libgpu_hip.so has no librccl dependency, and the exchange calls the
+ * copy of librccl the process already holds -- the one that made `nccl_comm`.  Search order: PBR_SetRcclLibrary(path) or
+ * env PBR_RCCL_LIB; an already mapped "librccl.so.1"; the process's global symbols; a fresh dlopen of librccl.so.1.
+ * PBR_SetRcclLibrary(NULL) forgets the binding (next use searches again).  PBR_RcclInfo: ncclGetVersion() code (e.g. 22707) and
+ * the file the entry points were bound from.  PBR_CommInfo: ncclCommCount / ncclCommUserRank of the caller's communicator. */
+int PBR_SetRcclLibrary(const char* path);
+int PBR_RcclInfo(int* version, const char** path);
+int PBR_CommInfo(void* nccl_comm, int* count, int* user_rank);
+/* ncclGroupStart; ncclRecv x n_recvs; ncclSend x n_sends; ncclGroupEnd (a rank may send to itself).  If a call inside the group
+ * fails, the group is still closed before PBR_E_COMM is returned (no dangling group on this thread); the communicator must then
+ * be treated as dead. */
 int PBR_ExchangeRanges(void* nccl_comm, void* stream, const PBR_XferRange* sends, uint32_t n_sends,
                        const PBR_XferRange* recvs, uint32_t n_recvs);
 /* The bytes of one work unit inside its texture: contiguous in the [mip][face][y][x] layout (rows of one face, or whole faces). */
@@ -106,7 +116,9 @@ uint32_t PBR_SelectUnits(const PBR_WorkUnit* units, uint32_t n, uint32_t level_m
  * i.e. early_mask = 2) are recorded into g_early behind whatever the caller already recorded there (the source's
  * GPU_OpGenerateMipmaps), the rest into g_late; both are submitted, then the early units travel on g_early's stream while
  * g_late computes, the late ones follow g_late.  The caller waits: GPU_GraphWait(g_late); GPU_GraphWait(g_early); and resets
- * the arena.  world == 1 runs both graphs and moves nothing.  Returns bytes sent / received by this rank, or PBR_E_*. */
+ * the arena.  world == 1 runs both graphs and moves nothing.  Returns bytes sent / received by this rank, or PBR_E_*.
+ * After a NEGATIVE return both graphs are nevertheless submitted: the caller must still GPU_GraphWait both, and must treat the
+ * communicator as dead (a failed early exchange means the late one was never issued; peers may be waiting in theirs). */
 int64_t PBR_RunPartitionedIBL(PBR_IBLPipelines* p, GPU_Graph* g_early, GPU_Graph* g_late, GPU_DescriptorArena* arena,
                               GPU_Texture* tex_env_cube, const PBR_IBLMaps* maps, void* nccl_comm, int root, int world, int rank,
                               uint32_t min_size, uint32_t early_mask);

@@ -18,12 +18,6 @@ uint64_t GPUX_TextureMipOffset(const GPU_Texture* t, uint32_t m) { uint64_t o = 
 uint64_t GPUX_TextureTotalBytes(const GPU_Texture* t) { return GPUX_TextureMipOffset(t, t->mip_level_count); }
 void* GPUX_TextureDevicePtr(GPU_Texture* t, uint32_t m) { (void)m; return (void*)(uintptr_t)(t->layer_count == 6 && t->mip_level_count > 1 ? 0x10000000u : 0x70000000u); }
 void GPUX_InvalidateTexture(GPU_Texture* t) { (void)t; }
-/* RCCL is never reached (no communicator) */
-int ncclGroupStart(void) { return 1; } int ncclGroupEnd(void) { return 1; }
-int ncclSend(const void* a, size_t b, int c, int d, void* e, void* f) { (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; return 1; }
-int ncclRecv(void* a, size_t b, int c, int d, void* e, void* f) { (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; return 1; }
-const char* ncclGetErrorString(int r) { (void)r; return "stub"; }
-
 #define CAP 4096
 static int cmp_range(const void* a, const void* b) {
     const PBR_XferRange* x = (const PBR_XferRange*)a; const PBR_XferRange* y = (const PBR_XferRange*)b;

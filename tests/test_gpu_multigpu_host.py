@@ -253,3 +253,72 @@ def test_gather_phases_cover_the_exchange_once_and_run_on_two_streams(gpu):
     finally:
         pbrhip.rccl_comm_destroy(comm)
     L.PBR_DestroyIBLMaps(C.byref(maps)); L.GPU_DestroyTexture(tex)
+
+
+_TORCH_FIRST = r"""
+import os, sys, ctypes as C
+import torch                                        # FIRST: maps torch's bundled librccl.so (SONAME librccl.so.1), as in bench.py
+sys.path.insert(0, os.path.join(sys.argv[1], "vulkan-pbr-renderer_amd", "python"))
+import pbrhip
+torch.cuda.set_device(0)
+L = pbrhip.init(device=0)
+ver, path = pbrhip.rccl_info()                      # what host/pbr_gather.c bound at first use
+print("RCCL", ver, path)
+comm = pbrhip.rccl_comm_init(1, 0, pbrhip.rccl_unique_id())
+assert pbrhip.comm_info(comm) == (1, 0)
+src = torch.arange(1 << 20, dtype=torch.float32, device="cuda") * 0.5 + 1.0
+dst = torch.zeros_like(src)
+g = L.GPU_MakeGraph()
+n = 7                                               # ragged pieces, each to self
+cuts = [0] + sorted(int(x) for x in torch.randint(1, src.numel() - 1, (n - 1,), generator=torch.Generator().manual_seed(5))) + [src.numel()]
+S = (pbrhip.PBR_XferRange * n)(*[pbrhip.PBR_XferRange(src.data_ptr() + 4 * a, 4 * (b - a), 0) for a, b in zip(cuts, cuts[1:])])
+R = (pbrhip.PBR_XferRange * n)(*[pbrhip.PBR_XferRange(dst.data_ptr() + 4 * a, 4 * (b - a), 0) for a, b in zip(cuts, cuts[1:])])
+torch.cuda.synchronize()
+assert L.PBR_ExchangeRanges(comm, L.GPUX_GraphStream(g), S, n, R, n) == 0
+L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)            # waits for the graph's stream, hence for the exchange
+torch.cuda.synchronize()
+assert torch.equal(src, dst)
+pbrhip.rccl_comm_destroy(comm)
+L.GPU_DestroyGraph(g); L.GPU_WaitUntilIdle(); L.GPU_Deinit()
+print("TORCH_FIRST_OK")
+"""
+
+
+def test_exchange_with_torch_imported_first(gpu, tmp_path):
+    """the library load order of bench.py -- torch first, so that the process's librccl.so.1 is torch's bundled
+    copy -- then a 1-rank communicator from that same copy and PBR_ExchangeRanges through the C host layer's run-time binding.
+    Runs in a child process (the test session itself has ROCm's librccl mapped by earlier tests)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "torch_first.py"
+    script.write_text(_TORCH_FIRST)
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "TORCH_FIRST_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("RCCL ")][0]
+    assert "torch" in line.split(" ", 2)[2], f"expected the exchange to bind torch's bundled librccl, got: {line}"
+
+
+def test_bench_launches_its_own_ranks(gpu):
+    """`python3 bench.py --gpus 2` with no launcher starts its two workers itself (child torch.distributed.run)
+    and returns their code; here as the gloo rehearsal on one GPU (RCCL refuses two ranks on one device), small workload, with
+    --check: the gathered result equals what one GPU computes alone, bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PBR_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "ref", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-shade", "--check"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
+    assert out["extra"]["check_gather_equals_single_gpu"] is True
+    assert out["extra"]["check_max_rel_err_vs_oracle"] < 1e-4
+    assert out["rccl"]["backend"] == "gloo" and out["step_split"]["bytes_sent_by_rank"][1] > 0

@@ -383,7 +383,7 @@ def test_partition_and_exchange_plan_under_sanitizers(tmp_path):
     here = os.path.dirname(os.path.abspath(__file__))
     root = os.path.dirname(here)
     flags = ["-std=c11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-w",
-             "-I" + os.path.join(root, "include"), "-I/opt/rocm/include"]
+             "-I" + os.path.join(root, "include")]
     srcs = [os.path.join(here, "sanitize", "fuzz_partition.c"), os.path.join(root, "vulkan-pbr-renderer_amd", "host", "pbr_gather.c"),
             os.path.join(root, "vulkan-pbr-renderer_amd", "host", "pbr_ibl.c")]
     objs = []
@@ -410,6 +410,74 @@ def test_partition_and_exchange_plan_under_sanitizers(tmp_path):
     assert b.returncode == 0, b.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.startswith("ok:"), (r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_c_gather_runs_at_world_2_3_5_8_against_stub_rccl(tmp_path):
+    """the REAL C exchange code (host/pbr_gather.c: PBR_GatherUnits, the two overlapped phases of
+    PBR_RunPartitionedIBL, PBR_GatherBands; host/pbr_ibl.c: PBR_PartitionIBL + PBR_RecordUnits) executed by N = 2, 3, 5, 8
+    PROCESSES on the CPU, under ASan + UBSan.  RCCL is replaced at its run-time binding point (PBR_SetRcclLibrary) by
+    tests/sanitize/nccl_stub.c (grouped send / recv over socket pairs, RCCL's matching rules), the kernels by a fake backend that
+    writes value(level, face, y, x) into exactly the rows a recorded dispatch covers.  Root: gathered maps == that function on every
+    texel (bit for bit), byte counts == the plan; peers: nothing but their own rows changed.  `failsend`: an ncclSend that fails
+    inside the group leaves GroupStart / GroupEnd balanced and the thread usable."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    flags = ["-std=c11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-w",
+             "-I" + os.path.join(root, "include")]
+    stub = str(tmp_path / "libnccl_stub.so")
+    exe = str(tmp_path / "gather_world")
+    b = subprocess.run(["gcc"] + flags + ["-shared", "-fPIC", os.path.join(here, "sanitize", "nccl_stub.c"), "-o", stub], capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr:
+        pytest.skip("toolchain without sanitizer runtimes")
+    assert b.returncode == 0, b.stderr[-2000:]
+    host = os.path.join(root, "vulkan-pbr-renderer_amd", "host")
+    b = subprocess.run(["gcc"] + flags + [os.path.join(here, "sanitize", "gather_world.c"), os.path.join(host, "pbr_gather.c"),
+                                         os.path.join(host, "pbr_ibl.c"), "-o", exe, "-ldl", "-lm"], capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr[-2000:]
+    cases = [(w, 256, 32, 1, m) for w in (2, 3, 5, 8) for m in ("units", "overlap", "bands")]
+    cases += [(1, 256, 32, 1, "units"), (1, 256, 32, 1, "overlap"), (3, 512, 0, 16, "overlap"), (2, 1024, 128, 1, "units"),
+              (3, 1024, 128, 1, "overlap"), (1, 64, 0, 1, "failsend")]
+    for (w, spec, irr, mn, mode) in cases:
+        r = subprocess.run([exe, stub, str(w), str(spec), str(irr), str(mn), mode], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.startswith("ok:"), ((w, spec, irr, mn, mode), r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_rccl_is_bound_at_first_use_not_at_link_time():
+    """libgpu_hip.so carries no librccl dependency (a single-GPU consumer neither loads nor needs it); the exchange
+    binds the library at first use and reports which file it took."""
+    import subprocess
+    import pbrhip
+    out = subprocess.run(["readelf", "-d", pbrhip.LIB_PATH], capture_output=True, text=True)
+    if out.returncode == 0:
+        assert "rccl" not in out.stdout and "nccl" not in out.stdout, out.stdout
+    L = pbrhip.lib()
+    assert L.PBR_SetRcclLibrary(b"/nonexistent/librccl.so") == -2            # PBR_E_COMM, loudly
+    assert L.PBR_ExchangeRanges(C.c_void_p(1), None, (pbrhip.PBR_XferRange * 1)(pbrhip.PBR_XferRange(1, 16, 0)), 1, None, 0) == -2
+    assert L.PBR_SetRcclLibrary(None) == 0                                    # back to the default search
+    if os.path.exists("/opt/rocm/lib/librccl.so.1"):
+        ver, path = pbrhip.rccl_info()
+        assert ver >= 20000 and "rccl" in path, (ver, path)
+
+
+def test_bench_dry_launch_prints_worker_command():
+    """`bench.py --gpus N --dry-launch` (no GPU, no torch import): the command the self-launch would start, rc 0."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--dry-launch"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    cmd = d["cmd"]
+    assert d["n_workers"] == 8 and "torch.distributed.run" in cmd and "--nproc-per-node=8" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "3"] and "--dry-launch" not in cmd and cmd[-5].endswith("bench.py")
+    # a launcher world that contradicts --gpus is an error, not a silent single-rank run
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120, env=env2)
+    assert r.returncode == 2 and "must agree" in r.stderr
 
 
 def test_public_headers_are_self_contained(tmp_path):

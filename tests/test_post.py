@@ -409,6 +409,28 @@ def test_gpu_frame_chain_hipgraph_replay_is_identical(gpu):
     L.GPUX_SetGraphReplay(0)
     L.GPUX_GraphReplayStats(graphs[0], C.byref(st[0]), C.byref(st[1]), C.byref(st[2]))
     assert np.array_equal(outs[0], outs[1]) and st[0].value == 6 and st[2].value == 2, [x.value for x in st]
+    # a graph whose earlier op rewrites a map that a later shade op samples (here: the mips of the prefiltered cube are
+    # regenerated, which drops its apron / cells twins at execution time) must not be captured -- the shade op would rebuild the
+    # twins (allocation + synchronisation) inside the capture.  It takes the plain path, and the frame equals the plain one.
+    glob = pbrhip.fill_globals(gbd["cam_pos"], aspect=W / H, frame_idx=0)
+    lit = []
+    for replay in (0, 1):
+        L.GPUX_SetGraphReplay(replay)
+        L.GPU_OpGenerateMipmaps(graphs[0], maps.tex_specular_env_map)
+        L.PBR_RecordLightingPass(lp, graphs[0], C.byref(glob), 0, 0)
+        L.GPU_GraphSubmit(graphs[0]); L.GPU_GraphWait(graphs[0])
+        lit.append(pbrhip.read_mip(gb.lighting_result, 0).copy())
+    L.GPUX_SetGraphReplay(0)
+    L.GPUX_GraphReplayStats(graphs[0], C.byref(st[0]), C.byref(st[1]), C.byref(st[2]))
+    assert st[0].value == 6, "a graph that rewrites a sampled map before shading must not go through a capture"
+    assert np.array_equal(lit[0].view(np.uint16), lit[1].view(np.uint16)) and float(lit[0].astype(np.float32).max()) > 0
+    # the same shade alone (twins rebuilt by the plain run above) is captured again
+    L.GPUX_SetGraphReplay(1)
+    L.PBR_RecordLightingPass(lp, graphs[0], C.byref(glob), 0, 0)
+    L.GPU_GraphSubmit(graphs[0]); L.GPU_GraphWait(graphs[0])
+    L.GPUX_SetGraphReplay(0)
+    L.GPUX_GraphReplayStats(graphs[0], C.byref(st[0]), C.byref(st[1]), C.byref(st[2]))
+    assert st[0].value == 7 and np.array_equal(pbrhip.read_mip(gb.lighting_result, 0).view(np.uint16), lit[0].view(np.uint16))
     for g in graphs:
         L.GPU_DestroyGraph(g)
     L.PBR_DestroyLightgrid(lg); L.PBR_DestroyPostProcess(pp); L.PBR_DestroyLightingPass(lp); L.PBR_DestroyGBuffer(C.byref(gb))

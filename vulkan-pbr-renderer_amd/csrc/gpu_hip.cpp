@@ -131,6 +131,11 @@ struct GPU_Graph {
     std::vector<hipEvent_t> ev;
     std::vector<std::string> timed_names;
     std::vector<float> timed_ms;
+    // one event pair on the graph's main stream around the whole submission (first op start .. last join): the busy span of the
+    // graph's kernels even when its dispatches overlap on side streams (the sum of per-op times would count the overlap twice)
+    hipEvent_t span_a = nullptr, span_b = nullptr;
+    bool span_recorded = false;
+    float span_ms = 0.0f;
 };
 
 struct DeviceTable { void* dev = nullptr; int count = 0; float alpha = 0.0f; };
@@ -723,6 +728,8 @@ GPU_API void GPU_DestroyGraph(GPU_Graph* g) {
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : g->sync_ev) (void)hipEventDestroy(e);
     if (g->order_ev) (void)hipEventDestroy(g->order_ev);
+    if (g->span_a) (void)hipEventDestroy(g->span_a);
+    if (g->span_b) (void)hipEventDestroy(g->span_b);
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (G.last_submitted == g) G.last_submitted = nullptr;        // idle by contract (gpu.h:453): nothing left to order against
     (void)hipStreamDestroy(g->stream);
@@ -1550,6 +1557,35 @@ static bool op_replayable(const Op& op) {
     return false;
 }
 
+// Graph-level eligibility.  op_replayable() looks at the sampler twins as they are NOW; an earlier op of the same graph that writes
+// one of the maps a later shade op samples (Op_Clear / Op_MipGen / Op_Blit / a storage-image dispatch drop the apron, cells and LUT
+// twins in exec_op) would have that shade op rebuild its twins -- allocation + synchronisation -- inside the capture.
+// Such a graph takes the plain path: the textures written by the ops seen so far are tracked and compared with what each shade
+// op samples.
+static bool graph_replayable(GPU_Graph* g) {
+    std::vector<const TextureImpl*> written;
+    auto is_written = [&](const TextureImpl* t) { for (const TextureImpl* w : written) if (w == t) return true; return false; };
+    for (const Op& op : g->ops) {
+        if (!op_replayable(op)) return false;
+        switch (op.kind) {
+        case Op_Clear: case Op_MipGen: written.push_back(op.tex); break;
+        case Op_Blit: if (op.tex2) written.push_back(op.tex2); break;          // tex = source, tex2 = destination
+        case Op_Dispatch: { Slot* o = named_slot(op.set, "IMG0"); if (o && o->tex) written.push_back(o->tex); break; }
+        case Op_Shade: {
+            KernelId k = op.gpipe->kernel;
+            if (k == Kernel_TaaResolve || k == Kernel_FinalPost || k == Kernel_BloomDown || k == Kernel_BloomUp) break;
+            for (const char* name : {"PREFILTERED_ENV_MAP", "TEX_IRRADIANCE_MAP", "BRDF_INTEGRATION_MAP"}) {
+                Slot* sl = named_slot(op.set, name);
+                if (sl && sl->tex && is_written(sl->tex)) return false;
+            }
+            break;
+        }
+        default: break;
+        }
+    }
+    return true;
+}
+
 GPU_API void GPUX_SetGraphReplay(int enable) { G.replay = enable < 0 ? -1 : (enable != 0); }
 GPU_API void GPUX_GraphReplayStats(GPU_Graph* g, uint64_t* launches, uint64_t* updates, uint64_t* instantiations) {
     if (!g) return;
@@ -1580,7 +1616,12 @@ GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
     G.last_submitted = g;
     if (G.replay < 0) { const char* e = getenv("PBR_GRAPH_REPLAY"); G.replay = e ? (atoi(e) != 0) : 0; }
     bool capture = G.replay == 1 && !G.timing && !g->replay_broken && !g->ops.empty();
-    if (capture) for (const Op& op : g->ops) if (!op_replayable(op)) { capture = false; break; }
+    if (capture) capture = graph_replayable(g);
+    g->span_recorded = false;
+    if (G.timing) {
+        if (!g->span_a) { HIP_OK(hipEventCreate(&g->span_a)); HIP_OK(hipEventCreate(&g->span_b)); }
+        HIP_OK(hipEventRecord(g->span_a, g->stream));
+    }
     if (capture && hipStreamBeginCapture(g->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); capture = false; g->replay_broken = true; }
     // Row-ranged precompute dispatches (the work units of a partitioned job) are too small to keep 256 CUs x 8 waves busy one
     // at a time: consecutive ones whose outputs are disjoint and which do not read each other's output go round-robin onto
@@ -1638,6 +1679,7 @@ GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
         g->cur = g->stream;
     }
     close_region();
+    if (G.timing) { HIP_OK(hipEventRecord(g->span_b, g->stream)); g->span_recorded = true; }
     if (capture) {
         hipGraph_t cg = nullptr;
         bool ok = hipStreamEndCapture(g->stream, &cg) == hipSuccess && cg;
@@ -1672,6 +1714,8 @@ GPU_API void GPU_GraphWait(GPU_Graph* g) {
         HIP_OK(hipEventElapsedTime(&ms, g->ev[2 * i], g->ev[2 * i + 1]));
         g->timed_ms.push_back(ms);
     }
+    g->span_ms = 0.0f;
+    if (g->span_recorded) { HIP_OK(hipEventElapsedTime(&g->span_ms, g->span_a, g->span_b)); g->span_recorded = false; }
     reset_graph(g);                      // Wait also resets the graph [gpu.h:452]
 }
 
@@ -1680,3 +1724,4 @@ GPU_API void GPUX_SetTileStreams(int count) { G.tile_streams = count < 0 ? -1 : 
 GPU_API uint32_t GPUX_GraphTimedOpCount(GPU_Graph* g) { return g ? (uint32_t)g->timed_ms.size() : 0; }
 GPU_API const char* GPUX_GraphTimedOpName(GPU_Graph* g, uint32_t i) { return (g && i < g->timed_names.size()) ? g->timed_names[i].c_str() : ""; }
 GPU_API float GPUX_GraphTimedOpMs(GPU_Graph* g, uint32_t i) { return (g && i < g->timed_ms.size()) ? g->timed_ms[i] : 0.0f; }
+GPU_API float GPUX_GraphSpanMs(GPU_Graph* g) { return g ? g->span_ms : 0.0f; }

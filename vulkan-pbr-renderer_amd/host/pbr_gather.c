@@ -8,17 +8,107 @@
  * initialises or destroys one.  Every transfer is a contiguous byte range: a unit is rows [row0,row1) of one face, or a
  * run of whole faces, of one level in the [mip][face][y][x] layout (PBR_UnitByteRange), a band is rows of a 2-D frame.
  * All ranks derive the same unit lists from PBR_PartitionIBL, so nothing but pixels crosses xGMI.
+ *
+ * RCCL is bound at FIRST USE, not at link time (round 3): a single-GPU consumer of libgpu_hip.so neither loads nor needs
+ * librccl, and a multi-GPU one gets the copy of librccl its own process already holds -- the one that created the
+ * communicator it passes in (an ncclComm_t is only meaningful to the library copy that made it).  Search order:
+ *   1. PBR_SetRcclLibrary(path) / environment PBR_RCCL_LIB           (explicit; also how the CPU tests plug in their stub)
+ *   2. dlopen("librccl.so.1", RTLD_NOLOAD)                           (already mapped: torch's bundled copy, or ROCm's)
+ *   3. the process's global scope (an application linked against RCCL or exporting the entry points itself)
+ *   4. dlopen("librccl.so.1"), then "librccl.so", then "/opt/rocm/lib/librccl.so.1"
  */
-#define __HIP_PLATFORM_AMD__ 1
-#include <rccl/rccl.h>
-
+#define _GNU_SOURCE 1
 #include "pbr_host.h"
 
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
-#define NCCL_OK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
-        fprintf(stderr, "GPU-ERROR: %s failed: %s\n", #call, ncclGetErrorString(r_)); return PBR_E_COMM; } } while (0)
+/* the five entry points of rccl.h that the exchange uses (+ three queries), by their C ABI: ncclResult_t is an int
+ * (ncclSuccess = 0), ncclDataType_t an int (ncclInt8 = 0), ncclComm_t and hipStream_t are pointers */
+typedef struct PBR_Rccl {
+    int (*GroupStart)(void);
+    int (*GroupEnd)(void);
+    int (*Send)(const void* buf, size_t count, int datatype, int peer, void* comm, void* stream);
+    int (*Recv)(void* buf, size_t count, int datatype, int peer, void* comm, void* stream);
+    const char* (*GetErrorString)(int);
+    int (*GetVersion)(int*);                  /* optional */
+    int (*CommCount)(void* comm, int*);       /* optional */
+    int (*CommUserRank)(void* comm, int*);    /* optional */
+    void* handle;
+    char  path[512];
+    int   resolved;                           /* 0 = not tried, 1 = bound, -1 = failed */
+} PBR_Rccl;
+static PBR_Rccl g_rccl;
+static char g_rccl_override[512];
+enum { NCCL_INT8 = 0 };
+
+static int rccl_bind_from(void* h) {
+    PBR_Rccl* R = &g_rccl;
+    *(void**)&R->GroupStart = dlsym(h, "ncclGroupStart");
+    *(void**)&R->GroupEnd = dlsym(h, "ncclGroupEnd");
+    *(void**)&R->Send = dlsym(h, "ncclSend");
+    *(void**)&R->Recv = dlsym(h, "ncclRecv");
+    *(void**)&R->GetErrorString = dlsym(h, "ncclGetErrorString");
+    *(void**)&R->GetVersion = dlsym(h, "ncclGetVersion");
+    *(void**)&R->CommCount = dlsym(h, "ncclCommCount");
+    *(void**)&R->CommUserRank = dlsym(h, "ncclCommUserRank");
+    if (!R->GroupStart || !R->GroupEnd || !R->Send || !R->Recv || !R->GetErrorString) return 0;
+    Dl_info info;
+    R->path[0] = 0;
+    if (dladdr(*(void**)&R->Send, &info) && info.dli_fname) snprintf(R->path, sizeof R->path, "%s", info.dli_fname);
+    return 1;
+}
+
+static int rccl_resolve(void) {
+    PBR_Rccl* R = &g_rccl;
+    if (R->resolved) return R->resolved > 0;
+    const char* explicit_path = g_rccl_override[0] ? g_rccl_override : getenv("PBR_RCCL_LIB");
+    void* h = NULL;
+    if (explicit_path && explicit_path[0]) {
+        h = dlopen(explicit_path, RTLD_NOW | RTLD_LOCAL);
+        if (!h) fprintf(stderr, "GPU-ERROR: RCCL library \"%s\" cannot be loaded: %s\n", explicit_path, dlerror());
+        else if (!rccl_bind_from(h)) { fprintf(stderr, "GPU-ERROR: \"%s\" lacks ncclGroupStart/End, ncclSend/Recv\n", explicit_path); dlclose(h); h = NULL; }
+        R->handle = h; R->resolved = h ? 1 : -1;
+        return h != NULL;
+    }
+    if ((h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD)) && rccl_bind_from(h)) { R->handle = h; R->resolved = 1; return 1; }
+    if (rccl_bind_from(RTLD_DEFAULT)) { R->handle = NULL; R->resolved = 1; return 1; }
+    static const char* const names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    for (unsigned i = 0; i < sizeof names / sizeof names[0]; ++i)
+        if ((h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL)) && rccl_bind_from(h)) { R->handle = h; R->resolved = 1; return 1; }
+    fprintf(stderr, "GPU-ERROR: the multi-GPU exchange needs librccl.so.1 and none could be loaded (%s); set PBR_RCCL_LIB\n", dlerror());
+    R->resolved = -1;
+    return 0;
+}
+
+int PBR_SetRcclLibrary(const char* path) {
+    if (g_rccl.resolved > 0 && g_rccl.handle) dlclose(g_rccl.handle);
+    memset(&g_rccl, 0, sizeof g_rccl);
+    g_rccl_override[0] = 0;
+    if (path && path[0]) {
+        if (strlen(path) >= sizeof g_rccl_override) return PBR_E_BADARG;
+        strcpy(g_rccl_override, path);
+        return rccl_resolve() ? PBR_OK : PBR_E_COMM;
+    }
+    return PBR_OK;
+}
+
+int PBR_RcclInfo(int* version, const char** path) {
+    if (!rccl_resolve()) return PBR_E_COMM;
+    if (version) { *version = 0; if (g_rccl.GetVersion) g_rccl.GetVersion(version); }
+    if (path) *path = g_rccl.path;
+    return PBR_OK;
+}
+
+int PBR_CommInfo(void* nccl_comm, int* count, int* user_rank) {
+    if (!nccl_comm) return PBR_E_BADARG;
+    if (!rccl_resolve()) return PBR_E_COMM;
+    if (count) { *count = -1; if (g_rccl.CommCount && g_rccl.CommCount(nccl_comm, count) != 0) return PBR_E_COMM; }
+    if (user_rank) { *user_rank = -1; if (g_rccl.CommUserRank && g_rccl.CommUserRank(nccl_comm, user_rank) != 0) return PBR_E_COMM; }
+    return PBR_OK;
+}
 
 int PBR_UnitByteRange(const PBR_IBLMaps* maps, const PBR_WorkUnit* u, GPU_Texture** tex, uint64_t* offset, uint64_t* bytes) {
     if (!maps || !u || !tex || !offset || !bytes) return PBR_E_BADARG;
@@ -48,13 +138,21 @@ int PBR_ExchangeRanges(void* nccl_comm, void* stream, const PBR_XferRange* sends
     for (uint32_t i = 0; i < n_sends; ++i) if (!sends[i].ptr || !sends[i].bytes || sends[i].peer < 0) return PBR_E_BADARG;
     for (uint32_t i = 0; i < n_recvs; ++i) if (!recvs[i].ptr || !recvs[i].bytes || recvs[i].peer < 0) return PBR_E_BADARG;
     if (n_sends + n_recvs == 0) return PBR_OK;
-    ncclComm_t comm = (ncclComm_t)nccl_comm;
-    hipStream_t st = (hipStream_t)stream;
-    /* one group: RCCL schedules every transfer of the step together (all peers' links at once) */
-    NCCL_OK(ncclGroupStart());
-    for (uint32_t i = 0; i < n_recvs; ++i) NCCL_OK(ncclRecv(recvs[i].ptr, recvs[i].bytes, ncclInt8, recvs[i].peer, comm, st));
-    for (uint32_t i = 0; i < n_sends; ++i) NCCL_OK(ncclSend(sends[i].ptr, sends[i].bytes, ncclInt8, sends[i].peer, comm, st));
-    NCCL_OK(ncclGroupEnd());
+    if (!rccl_resolve()) return PBR_E_COMM;
+    const PBR_Rccl* R = &g_rccl;
+    /* one group: RCCL schedules every transfer of the step together (all peers' links at once).  A call that fails inside
+     * the group must not leave the group open -- every later RCCL call of this thread would be queued into it and hang --
+     * so the error is remembered, the group is closed (its own result no longer matters) and PBR_E_COMM returned. */
+    int r = R->GroupStart();
+    if (r != 0) { fprintf(stderr, "GPU-ERROR: ncclGroupStart failed: %s\n", R->GetErrorString(r)); return PBR_E_COMM; }
+    int failed = 0; const char* what = "";
+    for (uint32_t i = 0; i < n_recvs && !failed; ++i)
+        if ((r = R->Recv(recvs[i].ptr, recvs[i].bytes, NCCL_INT8, recvs[i].peer, nccl_comm, stream)) != 0) { failed = r; what = "ncclRecv"; }
+    for (uint32_t i = 0; i < n_sends && !failed; ++i)
+        if ((r = R->Send(sends[i].ptr, sends[i].bytes, NCCL_INT8, sends[i].peer, nccl_comm, stream)) != 0) { failed = r; what = "ncclSend"; }
+    r = R->GroupEnd();
+    if (failed) { fprintf(stderr, "GPU-ERROR: %s failed: %s (group closed; treat the communicator as dead)\n", what, R->GetErrorString(failed)); return PBR_E_COMM; }
+    if (r != 0) { fprintf(stderr, "GPU-ERROR: ncclGroupEnd failed: %s\n", R->GetErrorString(r)); return PBR_E_COMM; }
     return PBR_OK;
 }
 
@@ -159,8 +257,9 @@ int64_t PBR_RunPartitionedIBL(PBR_IBLPipelines* p, GPU_Graph* g_early, GPU_Graph
     if (nl) PBR_RecordUnits(p, g_late, arena, tex_env_cube, maps, part, nl);
     GPU_GraphSubmit(g_late);
     free(units);
+    /* both graphs are in flight from here on: whatever is returned, the caller must GPU_GraphWait both (pbr_host.h) */
     int64_t b0 = PBR_GatherUnitsMasked(nccl_comm, GPUX_GraphStream(g_early), root, world, rank, maps, min_size, env_size, early_mask);
-    if (b0 < 0) return b0;
+    if (b0 < 0) return b0;                                   /* the late exchange is not issued: the communicator is dead */
     int64_t b1 = PBR_GatherUnitsMasked(nccl_comm, GPUX_GraphStream(g_late), root, world, rank, maps, min_size, env_size, ~early_mask);
     if (b1 < 0) return b1;
     return b0 + b1;

@@ -170,7 +170,7 @@ PROTOTYPES = {
     "GPUX_TextureTotalBytes": (C.c_uint64, [TexP]), "GPUX_TextureMipOffset": (C.c_uint64, [TexP, U32]),
     "GPUX_MakeCubemapFromEquirect": (TexP, [VP, U32, U32, U32, C.c_int]),
     "GPUX_GraphStream": (VP, [VP]), "GPUX_EnableOpTiming": (None, [C.c_int]), "GPUX_SetTileStreams": (None, [C.c_int]), "GPUX_GraphTimedOpCount": (U32, [VP]),
-    "GPUX_GraphTimedOpName": (C.c_char_p, [VP, U32]), "GPUX_GraphTimedOpMs": (C.c_float, [VP, U32]),
+    "GPUX_GraphTimedOpName": (C.c_char_p, [VP, U32]), "GPUX_GraphTimedOpMs": (C.c_float, [VP, U32]), "GPUX_GraphSpanMs": (C.c_float, [VP]),
     # --- host layer (include/pbr_host.h) ---
     "PBR_DecodeHDR": (VP, [VP, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
     "PBR_MakeTextureFromHDRIMemory": (TexP, [VP, C.c_size_t]), "PBR_MakeTextureFromHDRIFile": (TexP, [C.c_char_p]),
@@ -184,6 +184,8 @@ PROTOTYPES = {
     "PBR_RecordUnits": (None, [VP, VP, VP, TexP, C.POINTER(PBR_IBLMaps), C.POINTER(PBR_WorkUnit), U32]),
     "PBR_PartitionIBL": (U32, [U32, U32, U32, U32, C.c_int, C.c_int, C.POINTER(PBR_WorkUnit), U32]),
     "PBR_ExchangeRanges": (C.c_int, [VP, VP, VP, U32, VP, U32]),
+    "PBR_SetRcclLibrary": (C.c_int, [C.c_char_p]), "PBR_RcclInfo": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
+    "PBR_CommInfo": (C.c_int, [VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "PBR_UnitByteRange": (C.c_int, [C.POINTER(PBR_IBLMaps), C.POINTER(PBR_WorkUnit), C.POINTER(TexP), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "PBR_GatherUnits": (C.c_int64, [VP, VP, C.c_int, C.c_int, C.c_int, C.POINTER(PBR_IBLMaps), U32, U32]),
     "GPUX_SetGraphReplay": (None, [C.c_int]),
@@ -341,18 +343,35 @@ class NcclUniqueId(C.Structure):
 _RCCL = None
 
 
+def rccl_info():
+    """(ncclGetVersion code, path of the librccl the C host layer bound) -- PBR_RcclInfo; raises if none can be loaded."""
+    ver, path = C.c_int(0), C.c_char_p()
+    if lib().PBR_RcclInfo(C.byref(ver), C.byref(path)) != 0:
+        raise RuntimeError("no librccl.so.1 could be bound (PBR_RCCL_LIB / PBR_SetRcclLibrary select one explicitly)")
+    return int(ver.value), (path.value or b"").decode()
+
+
 def rccl():
-    """librccl as libgpu_hip.so sees it (same SONAME: one copy per process)."""
+    """The SAME librccl the C host layer calls (PBR_RcclInfo names the file; one copy per process by SONAME), so that a
+    communicator made here is valid for PBR_GatherUnits / PBR_GatherBands / PBR_ExchangeRanges."""
     global _RCCL
     if _RCCL is None:
-        lib()                                             # loads libgpu_hip.so, which pulls librccl.so.1 in
-        R = C.CDLL("librccl.so.1")
+        _, path = rccl_info()
+        R = C.CDLL(path or "librccl.so.1")
         R.ncclGetUniqueId.argtypes = [C.POINTER(NcclUniqueId)]; R.ncclGetUniqueId.restype = C.c_int
         R.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, NcclUniqueId, C.c_int]; R.ncclCommInitRank.restype = C.c_int
         R.ncclCommDestroy.argtypes = [C.c_void_p]; R.ncclCommDestroy.restype = C.c_int
         R.ncclGetErrorString.argtypes = [C.c_int]; R.ncclGetErrorString.restype = C.c_char_p
         _RCCL = R
     return _RCCL
+
+
+def comm_info(comm):
+    """(rank count, this rank) as the communicator itself reports them (ncclCommCount / ncclCommUserRank)."""
+    n, r = C.c_int(-1), C.c_int(-1)
+    if lib().PBR_CommInfo(comm, C.byref(n), C.byref(r)) != 0:
+        raise RuntimeError("PBR_CommInfo failed")
+    return int(n.value), int(r.value)
 
 
 def rccl_unique_id():
