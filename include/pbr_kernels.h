@@ -152,6 +152,16 @@ typedef struct PbrkShadeArgs {
     float globals[138];                 /* RendererGlobalsBuffer, render.h:122-136 (552 bytes) */
 } PbrkShadeArgs;
 int pbrk_shade(const PbrkShadeArgs* args, void* stream);
+/* The modes without sun shadows / voxel GI have two instantiations with bit-identical results: k_shade_fast (64 x 4 pixel
+ * workgroups, every tap through the texture path; the default) and k_shade_tile (64 x 4 pixel tiles whose prefiltered taps come
+ * from LDS-staged windows placed by the tile's centre pixel; measured slower on MI355X -- DESIGN.md K5 -- and therefore opt-in:
+ * frames of at least `pixels` pixels take it; default: never, env PBR_SHADE_TILE_MIN_PIXELS; < 0 restores the default).  Both
+ * read per-column / per-row tables of the frame size ((x + .5) / W * 2 - 1 and the interleaved-gradient-noise products, computed
+ * on the host in the shader's operation order); pbrk_shade_tables_ready: they exist (the first launch of a frame size builds
+ * them with a synchronous upload, so that launch cannot be part of a stream capture: pbrk_shade_needs_tables). */
+void pbrk_shade_set_tile_min_pixels(long long pixels);
+int pbrk_shade_tables_ready(int width, int height);
+int pbrk_shade_needs_tables(int width, int height);     /* the next launch of this frame size would build them (not capturable) */
 /* LUT twin for K5: one 16-byte load per bilinear LUT fetch */
 int pbrk_lut_cells_build(const void* lut_half2, int size, void* cells_out, void* stream);
 

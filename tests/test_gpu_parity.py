@@ -292,6 +292,52 @@ def test_shade_random_bytes_all_decodes(gpu):
     gpu.PBR_DestroyIBLMaps(C.byref(maps)); gpu.GPU_DestroyTexture(env_tex)
 
 
+@pytest.mark.parametrize("size,mode", [((333, 131), "ibl"), ((1000, 564), "ibl"), ((640, 360), "shafts"), ((256, 144), "sun_only")])
+def test_shade_tile_kernel_equals_fast_kernel_and_oracle(gpu, size, mode):
+    """K5's tiled instantiation (k_shade_tile.hip: prefiltered taps from LDS-staged windows placed by each 64 x 16 tile's centre
+    pixel, per-column / per-row host tables) against the fast instantiation: the same bits on every pixel, for frame sizes that are
+    not multiples of the tile, row bands cut inside tiles, all three fast modes; plus the oracle at 1e-4.  The spheres scene at these
+    sizes has tiles whose lanes fall outside their windows (sphere silhouettes, face changes), so both the LDS and the fallback
+    path of one wave are exercised; random bytes make every lane a fallback."""
+    import pbrhip, pbr_oracle as O
+    W, H = size
+    gbd, env_tex, maps, gb, lp, glob = _shade_setup(gpu, W, H, pbrhip.Format_RGBA32F)
+    flags, oflags = {"ibl": (pbrhip.Shade_IBL, O.SHADE_IBL), "shafts": (pbrhip.Shade_IBL | pbrhip.Shade_LightShafts, O.SHADE_IBL | O.SHADE_SHAFTS),
+                     "sun_only": (0, 0)}[mode]
+    gpu.GPUX_SetShadeFlags(gpu.PBR_LightingPipeline(lp), flags)
+    glob = pbrhip.fill_globals(gbd["cam_pos"], aspect=W / H, frame_idx=23)
+    g = gpu.GPU_MakeGraph()
+
+    def run(tile, bands):
+        gpu.pbrk_shade_set_tile_min_pixels(0 if tile else 1 << 40)
+        gpu.GPU_OpClearColorF(g, gb.lighting_result, 0, -7.0, -7.0, -7.0, -7.0)
+        for (r0, r1) in bands:
+            gpu.PBR_RecordLightingPass(lp, g, C.byref(glob), r0, r1)
+        gpu.GPU_GraphSubmit(g); gpu.GPU_GraphWait(g)
+        return pbrhip.read_mip(gb.lighting_result, 0).copy()
+
+    try:
+        fast = run(False, [(0, 0)])
+        tile = run(True, [(0, 0)])
+        assert np.array_equal(fast.view(np.uint32), tile.view(np.uint32)), int((fast.view(np.uint32) != tile.view(np.uint32)).any(-1).sum())
+        banded = run(True, [(0, 5), (5, 37), (37, H - 1), (H - 1, H)])            # bands that start and end inside tiles
+        assert np.array_equal(banded.view(np.uint32), tile.view(np.uint32))
+        want = _oracle_shade(gpu, gbd, maps, glob, oflags)
+        assert rel_err(tile[..., :3], want[..., :3], floor=1e-2) < REL, rel_err(tile[..., :3], want[..., :3], floor=1e-2)
+        if mode == "ibl":                                                           # wild inputs: every lane its own direction
+            rng = np.random.default_rng(0x5EED00AF)
+            for name, key in (("base_color", "base"), ("normal", "normal"), ("orm", "orm"), ("emissive", "emissive")):
+                pbrhip.upload_mip(getattr(gb, name), 0, rng.integers(0, 256, (H, W, 4), dtype=np.uint8))
+            depth = (0.9980 + 0.0019 * rng.random((H, W))).astype(np.float32); depth[rng.random((H, W)) < 0.2] = 1.0
+            pbrhip.upload_mip(gb.depth, 0, depth)
+            a, b = run(False, [(0, 0)]), run(True, [(0, 0)])
+            assert not np.isnan(b).any() and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    finally:
+        gpu.pbrk_shade_set_tile_min_pixels(-1)
+    gpu.GPU_DestroyGraph(g); gpu.PBR_DestroyLightingPass(lp); gpu.PBR_DestroyGBuffer(C.byref(gb))
+    gpu.PBR_DestroyIBLMaps(C.byref(maps)); gpu.GPU_DestroyTexture(env_tex)
+
+
 @pytest.mark.parametrize("mode", ["live_shafts_shadows", "ibl_shadows"])
 def test_shade_sun_shadows_vs_oracle(gpu, mode):
     """lighting_pass.glsl:594-608 (4-tap PCF sun shadow) and :646 (light-shaft visibility) with a synthetic sun depth map bound to

@@ -1551,6 +1551,7 @@ static bool op_replayable(const Op& op) {
             if (!irr->bordered_valid || irr->bordered_from > 0 || !cells_ready(irr, 0)) return false;
             if (!named_slot(s, "BRDF_INTEGRATION_MAP")->tex->lut_cells_valid) return false;
         }
+        if (op.pass && pbrk_shade_needs_tables((int)op.pass->desc.width, (int)op.pass->desc.height)) return false;    // first tiled launch of a frame size builds its tables
         return named_slot(s, "GLOBALS")->buf->pinned_host;
     }
     }

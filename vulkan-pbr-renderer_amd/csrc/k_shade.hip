@@ -537,6 +537,62 @@ extern "C" int pbrk_debug_sample(int which, const void* texture, int w, int h, i
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
 
+// Per-column / per-row tables of a frame size for k_shade_tile (lighting_pass.glsl:444-447, 456-459 and InterleavedGradientNoise
+// :119-121), in the shader's operation order with correctly rounded fp32 operations:
+//   col[x] = { (x + .5) / W * 2 - 1, .06711056 (x + .5), .06711056 ((x + .5) + 90), .06711056 ((x + .5) + 522) }
+//   row[y] = { (y + .5) / H * 2 - 1, .00583715 (y + .5), .00583715 ((y + .5) + 20), .00583715 ((y + .5) + 55) }
+// Built once per frame size (synchronous upload: never inside a stream capture -- pbrk_shade_tables_ready tells the backend).
+#include <map>
+#include <mutex>
+#include <vector>
+struct ShadeTables { float4* col = nullptr; float4* row = nullptr; };
+static std::map<std::pair<int, int>, ShadeTables> g_shade_tables;
+static std::mutex g_shade_tables_mu;
+extern "C" int pbrk_shade_tables_ready(int width, int height) {
+    std::lock_guard<std::mutex> lk(g_shade_tables_mu);
+    return g_shade_tables.count({width, height}) ? 1 : 0;
+}
+static long long g_tile_min_pixels = -1;        // -1: PBR_SHADE_TILE_MIN_PIXELS or the default
+extern "C" void pbrk_shade_set_tile_min_pixels(long long pixels) { g_tile_min_pixels = pixels; }
+static long long tile_min_pixels() {
+    if (g_tile_min_pixels < 0) { const char* e = getenv("PBR_SHADE_TILE_MIN_PIXELS"); g_tile_min_pixels = e ? atoll(e) : (1ll << 62); }
+    return g_tile_min_pixels;
+}
+// 1 when the next launch for this frame size would still have to build (allocate + upload) its tables
+extern "C" int pbrk_shade_needs_tables(int width, int height) {
+    static int tab = -1;
+    if (tab < 0) { const char* e = getenv("PBR_SHADE_TABLES"); tab = e ? atoi(e) : 0; }
+    return (tab || (long long)width * height >= tile_min_pixels()) && !pbrk_shade_tables_ready(width, height);
+}
+static bool shade_tables(int width, int height, const float4** col, const float4** row) {
+    std::lock_guard<std::mutex> lk(g_shade_tables_mu);
+    auto it = g_shade_tables.find({width, height});
+    if (it == g_shade_tables.end()) {
+        std::vector<float4> hc((size_t)width), hr((size_t)height);
+        const float wf = (float)width, hf = (float)height;
+        for (int x = 0; x < width; ++x) {
+            const float fc = (float)x + 0.5f;
+            const float u = fc / wf;
+            float4 v; v.x = u * 2.0f - 1.0f; v.y = 0.06711056f * fc; v.z = 0.06711056f * (fc + 90.0f); v.w = 0.06711056f * (fc + 522.0f);
+            hc[(size_t)x] = v;
+        }
+        for (int y = 0; y < height; ++y) {
+            const float fc = (float)y + 0.5f;
+            const float u = fc / hf;
+            float4 v; v.x = u * 2.0f - 1.0f; v.y = 0.00583715f * fc; v.z = 0.00583715f * (fc + 20.0f); v.w = 0.00583715f * (fc + 55.0f);
+            hr[(size_t)y] = v;
+        }
+        ShadeTables t;
+        if (hipMalloc((void**)&t.col, hc.size() * sizeof(float4)) != hipSuccess) return false;
+        if (hipMalloc((void**)&t.row, hr.size() * sizeof(float4)) != hipSuccess) { (void)hipFree(t.col); return false; }
+        if (hipMemcpy(t.col, hc.data(), hc.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(t.row, hr.data(), hr.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(t.col); (void)hipFree(t.row); return false; }
+        it = g_shade_tables.emplace(std::make_pair(width, height), t).first;
+    }
+    *col = it->second.col; *row = it->second.row;
+    return true;
+}
+
 extern "C" int pbrk_shade(const PbrkShadeArgs* a, void* stream) {
     if (!a || a->width < 1 || a->height < 1) return PBRK_E_ARG;
     if (a->x0 < 0 || a->y0 < 0 || a->x1 > a->width || a->y1 > a->height || a->x0 >= a->x1 || a->y0 >= a->y1) return PBRK_E_ARG;
@@ -586,6 +642,34 @@ extern "C" int pbrk_shade(const PbrkShadeArgs* a, void* stream) {
         size_t cb = 0;
         for (int l = 0; l < a->prefiltered_levels; ++l) { int n = a->prefiltered_size >> l; if (n < 1) n = 1; cb += pbrk_cells_bytes(n); }
         p.pre_cells_bytes = (int)cb;
+        // tiled instantiation (LDS-staged windows of the prefiltered levels + per-column / per-row host tables): frames from
+        // PBR_SHADE_TILE_MIN_PIXELS on (a tile must subtend a small solid angle for its windows to cover its taps); the choice
+        // depends on the FRAME's size only, so a row-banded dispatch runs the same kernel as the whole frame
+        if ((long long)a->width * a->height >= tile_min_pixels() && shade_tables(a->width, a->height, &p.col_tab, &p.row_tab)) {
+            p.irr_nf = (float)p.irr_size; p.irr_off1 = 0.5f * p.irr_nf + 0.5f;
+            p.noise_offset = (1000 * 1.61803398875f) * p.frame_idx_mod_59;
+            p.pre_maxl = (float)(p.pre_levels - 1); p.pre_wf = (float)p.pre_size; p.lut_sf = (float)p.lut_size;
+            p.dbg = 0; p.dbg_stats = nullptr;
+#ifdef PBR_K5_DEBUG
+            {   // diagnostics build: PBR_K5_DBG bits (k_shade_internal.h); counters printed at every 16th launch
+                static int dbg = -1; static unsigned long long* stats = nullptr; static int launches = 0;
+                if (dbg < 0) { const char* e = getenv("PBR_K5_DBG"); dbg = e ? atoi(e) : 0; }
+                if ((dbg & 4) && !stats) { (void)hipMalloc((void**)&stats, 64); (void)hipMemset(stats, 0, 64); }
+                p.dbg = dbg; p.dbg_stats = stats;
+                if ((dbg & 4) && (++launches % 8) == 0) {
+                    unsigned long long h[6]; (void)hipDeviceSynchronize(); (void)hipMemcpy(h, stats, 48, hipMemcpyDeviceToHost);
+                    fprintf(stderr, "k5 tile: %llu fetching lanes, %.1f %% in window A, %.1f %% in window B; %llu waves, %.1f %% all-A, %.1f %% all-B\n",
+                            h[0], 100.0 * h[1] / h[0], 100.0 * h[2] / h[0], h[3], 100.0 * h[4] / h[3], 100.0 * h[5] / h[3]);
+                    (void)hipMemset(stats, 0, 64);
+                }
+            }
+#endif
+            return launch_shade_tile(p, (a->flags & PBRK_SHADE_IBL) != 0, (a->flags & PBRK_SHADE_SHAFTS) != 0, (hipStream_t)stream);
+        }
+        p.col_tab = nullptr; p.row_tab = nullptr;
+        static int tab = -1;
+        if (tab < 0) { const char* e = getenv("PBR_SHADE_TABLES"); tab = e ? atoi(e) : 0; }
+        if (tab) (void)shade_tables(a->width, a->height, &p.col_tab, &p.row_tab);
         return launch_shade_fast(p, (a->flags & PBRK_SHADE_IBL) != 0, (a->flags & PBRK_SHADE_SHAFTS) != 0, (hipStream_t)stream);
     }
     if (a->flags & PBRK_SHADE_GI) hipLaunchKernelGGL(k_shade<true>, dim3((p.w + 31) / 32, (p.h + 7) / 8), dim3(256), 0, (hipStream_t)stream, p);

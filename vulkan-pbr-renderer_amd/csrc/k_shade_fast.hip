@@ -32,12 +32,21 @@ __device__ __forceinline__ f3 pre_level_fetch(__amdgpu_buffer_rsrc_t rc, float f
     return cells_bilerp(bl4(rc, off), bl4(rc, off + 16), bl4(rc, off + 32), a, b);
 }
 
-template <bool kIBL, bool kShafts>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shade_fast(const ShadeParams p) {
+// kStride: which pixels share a wave.  1: 64 consecutive pixels of a row (workgroup = 64 x 4 pixels).  9: every 9th pixel of a
+// 576-pixel row segment, the nine waves of a workgroup interleaved (wave j takes x = 9 k + j).  The shader jitters the reflection
+// vector with InterleavedGradientNoise (:119-121, :456-459, :695), fract(52.9829189 fract(.06711056 x + .00583715 y)): one pixel
+// to the right advances the outer argument by 3.5557, nine pixels by 32.0014 -- an integer to 1.4e-3 -- so pixels nine apart get
+// (almost) the same three noise values, hence the same jitter, and their reflection vectors differ by what nine pixels of
+// geometry turn them: half a texel of the prefiltered level instead of the +-6 to 12 texels the jitter spreads neighbours over.
+// The six 16-byte taps of adjacent lanes then fall into the same or adjacent cells (coherent through the texture path); the price
+// is G-buffer loads and stores with a 36- / 72-byte lane pitch, whose lines the nine waves of the workgroup share through L1 / L2.
+template <bool kIBL, bool kShafts, int kStride, bool kTab = false>
+__global__ __launch_bounds__(kStride == 1 ? 256 : 576) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shade_fast(const ShadeParams p) {
     __shared__ int lv_off[16];        // byte offset of level l inside the prefiltered cells twin
     if (threadIdx.x < 16) lv_off[threadIdx.x] = cells_level_off(p.pre_size, 0, min((int)threadIdx.x, p.pre_levels - 1)) * 16;
     __syncthreads();
-    const int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int lx = kStride == 1 ? blockIdx.x * 64 + (threadIdx.x & 63) : blockIdx.x * (64 * kStride) + (threadIdx.x & 63) * kStride + (threadIdx.x >> 6);
+    const int ly = kStride == 1 ? blockIdx.y * 4 + (threadIdx.x >> 6) : blockIdx.y;
     if (lx >= p.w || ly >= p.h) return;
     const int px = p.x0 + lx, py = p.y0 + ly;
     const int pi4 = (py * p.width + px) * 4;                          // all five G-buffer planes hold 4 bytes per pixel
@@ -78,22 +87,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
 
     // :444-451 (exact)
-    SharedRcp rw, rh;
-    rw.d = (float)p.width; rw.r = p.rcp_width; rh.d = (float)p.height; rh.r = p.rcp_height;
     const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
-    const float xn = fmaf(div_by(fcx, rw), 2.0f, -1.0f), yn = fmaf(div_by(fcy, rh), 2.0f, -1.0f);     // 2u is exact: (u*2) - 1
+    float xn, yn, noise_1, noise_2, noise_3;
+    const float noise_offset = (1000 * 1.61803398875f) * p.frame_idx_mod_59;
+    if (kTab) {
+        // per-column / per-row constants from the host tables (k_shade.hip shade_tables: the same operations, correctly rounded):
+        // col[x] = { xn, .06711056 fcx, .06711056 (fcx + 90), .06711056 (fcx + 522) }, row[y] likewise with .00583715 and 20 / 55
+        __amdgpu_buffer_rsrc_t rcol = __builtin_amdgcn_make_buffer_rsrc((void*)p.col_tab, 0, p.width * 16, 0x00020000);
+        const float4 ct = bl4(rcol, px * 16);
+        typedef float v4ft __attribute__((ext_vector_type(4)));
+        const v4ft rt = ((const __attribute__((address_space(4))) v4ft*)p.row_tab)[__builtin_amdgcn_readfirstlane(py)];     // a wave is one row: scalar load
+        xn = ct.x; yn = rt.x;
+        noise_1 = __builtin_amdgcn_fractf(__builtin_amdgcn_fractf(52.9829189f * __builtin_amdgcn_fractf(ct.y + rt.y)) + noise_offset);
+        noise_2 = __builtin_amdgcn_fractf(__builtin_amdgcn_fractf(52.9829189f * __builtin_amdgcn_fractf(ct.z + rt.z)) + noise_offset);
+        noise_3 = __builtin_amdgcn_fractf(__builtin_amdgcn_fractf(52.9829189f * __builtin_amdgcn_fractf(ct.w + rt.w)) + noise_offset);
+    } else {
+        SharedRcp rw, rh;
+        rw.d = (float)p.width; rw.r = p.rcp_width; rh.d = (float)p.height; rh.r = p.rcp_height;
+        xn = fmaf(div_by(fcx, rw), 2.0f, -1.0f); yn = fmaf(div_by(fcy, rh), 2.0f, -1.0f);     // 2u is exact: (u*2) - 1
+        // :456-459 (exact; x - floor(x) == v_fract for the non-negative arguments here)
+        auto ignf = [](float x, float y) { return __builtin_amdgcn_fractf(52.9829189f * __builtin_amdgcn_fractf(0.06711056f * x + 0.00583715f * y)); };
+        noise_1 = __builtin_amdgcn_fractf(ignf(fcx, fcy) + noise_offset);
+        noise_2 = __builtin_amdgcn_fractf(ignf(fcx + 90.0f, fcy + 20.0f) + noise_offset);
+        noise_3 = __builtin_amdgcn_fractf(ignf(fcx + 522.0f, fcy + 55.0f) + noise_offset);
+    }
     float pw[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) pw[r] = ((p.wfc[r] * xn + p.wfc[4 + r] * yn) + p.wfc[8 + r] * depth) + p.wfc[12 + r];
     SharedRcp rpw; rpw.d = pw[3]; rpw.r = rcp_nr(pw[3]);
     const f3 P = mk3(div_by(pw[0], rpw), div_by(pw[1], rpw), div_by(pw[2], rpw));
-
-    // :456-459 (exact; x - floor(x) == v_fract for the non-negative arguments here)
-    const float noise_offset = (1000 * 1.61803398875f) * p.frame_idx_mod_59;
-    auto ignf = [](float x, float y) { return __builtin_amdgcn_fractf(52.9829189f * __builtin_amdgcn_fractf(0.06711056f * x + 0.00583715f * y)); };
-    const float noise_1 = __builtin_amdgcn_fractf(ignf(fcx, fcy) + noise_offset);
-    const float noise_2 = __builtin_amdgcn_fractf(ignf(fcx + 90.0f, fcy + 20.0f) + noise_offset);
-    const float noise_3 = __builtin_amdgcn_fractf(ignf(fcx + 522.0f, fcy + 55.0f) + noise_offset);
 
     const f3 cam = mk3(p.cam[0], p.cam[1], p.cam[2]);
     const f3 V = normalize3_nr(sub3(cam, P));                                          // :612 (exact)
@@ -213,10 +235,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 }
 
 int launch_shade_fast(const ShadeParams& p, bool ibl, bool shafts, hipStream_t stream) {
+    static int stride9 = -1;
+    if (stride9 < 0) { const char* e = getenv("PBR_SHADE_STRIDE9"); stride9 = e ? atoi(e) : 0; }
+    // kTab: measured SLOWER than recomputing (8K frame 564-576 vs 540-544 us, 1080p 24.8 vs 23.3 us: 24 fewer VALU instructions do not
+    // pay for one more vector-memory instruction per wave -- the kernel is bound by its memory instructions); opt-in
+    static int tab = -1;
+    if (tab < 0) { const char* e = getenv("PBR_SHADE_TABLES"); tab = e ? atoi(e) : 0; }
+    if (tab && p.col_tab && p.row_tab) {
+        dim3 grid((p.w + 63) / 64, (p.h + 3) / 4);
+        if (ibl && shafts) hipLaunchKernelGGL((k_shade_fast<true, true, 1, true>), grid, dim3(256), 0, stream, p);
+        else if (ibl) hipLaunchKernelGGL((k_shade_fast<true, false, 1, true>), grid, dim3(256), 0, stream, p);
+        else if (shafts) hipLaunchKernelGGL((k_shade_fast<false, true, 1, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((k_shade_fast<false, false, 1, true>), grid, dim3(256), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+    }
+    if (stride9 && ibl && !shafts) {
+        dim3 grid((p.w + 575) / 576, p.h);
+        hipLaunchKernelGGL((k_shade_fast<true, false, 9>), grid, dim3(576), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+    }
     dim3 grid((p.w + 63) / 64, (p.h + 3) / 4);
-    if (ibl && shafts) hipLaunchKernelGGL((k_shade_fast<true, true>), grid, dim3(256), 0, stream, p);
-    else if (ibl) hipLaunchKernelGGL((k_shade_fast<true, false>), grid, dim3(256), 0, stream, p);
-    else if (shafts) hipLaunchKernelGGL((k_shade_fast<false, true>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((k_shade_fast<false, false>), grid, dim3(256), 0, stream, p);
+    if (ibl && shafts) hipLaunchKernelGGL((k_shade_fast<true, true, 1>), grid, dim3(256), 0, stream, p);
+    else if (ibl) hipLaunchKernelGGL((k_shade_fast<true, false, 1>), grid, dim3(256), 0, stream, p);
+    else if (shafts) hipLaunchKernelGGL((k_shade_fast<false, true, 1>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((k_shade_fast<false, false, 1>), grid, dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }

@@ -18,6 +18,10 @@ struct ShadeParams {
     float ssw[16];       // sun_space_from_world (light shafts only)
     float sun[3], cam[3], frame_idx_mod_59;
     float rcp_width, rcp_height;   // RN(1/width), RN(1/height), computed on the host
+    // tiled instantiation (k_shade_tile.hip): per-column / per-row tables of the frame and wave-uniform constants, all computed on the host
+    const float4* col_tab; const float4* row_tab;
+    float irr_nf, irr_off1, noise_offset, pre_maxl, pre_wf, lut_sf;
+    int dbg; void* dbg_stats;      // -DPBR_K5_DEBUG builds only (tools/k5_tile_probe.sh): 1 = no staging, 2 = every lane reads LDS, 4 = window hit counters
     const float* sun_depth; int sun_w, sun_h;
     // voxel GI (PBRK_SHADE_GI)
     const uint2* grid; int grid_n;
@@ -48,3 +52,5 @@ __device__ __forceinline__ int cells_level_off(int W, int first, int level) {
 
 // k_shade_fast.hip
 int launch_shade_fast(const ShadeParams& p, bool ibl, bool shafts, hipStream_t stream);
+// k_shade_tile.hip
+int launch_shade_tile(const ShadeParams& p, bool ibl, bool shafts, hipStream_t stream);
