@@ -117,6 +117,8 @@ int pbrk_mc_filter(const void* src_bordered_level, const void* src_cells, int n_
 int pbrk_mc_region_stats(unsigned long long* out2, int reset);
 /* the binning's yield with the same switch: {(region, sample) flags set, samples x tiles, regions visited} summed over all tiles since the last reset */
 int pbrk_mc_region_flag_stats(unsigned long long* out3);
+/* samples that binning proved to tap one region from every texel of their tile (they run the body without tests), summed over tiles */
+int pbrk_mc_region_window_stats(unsigned long long* out1);
 
 /* ---- K5: deferred shade pass (shaders/lighting_pass.glsl:432-716, in-scope sub-blocks). */
 typedef struct PbrkShadeArgs {

@@ -191,6 +191,47 @@ def test_shade_fp16_target(gpu):
     gpu.PBR_DestroyIBLMaps(C.byref(maps)); gpu.GPU_DestroyTexture(env_tex)
 
 
+def test_shade_fp16_overflow_store(gpu):
+    """The RGBA16F store of values beyond the half range: lighting_pass.glsl:712 clamps the colour
+    from below only, and at low roughness the sun term reaches 1e5 (D = 1 / (pi a^2) at N.H = 1).  Defined here as the IEEE
+    round-to-nearest-even conversion: fp32 values from 65520 on store +inf (0x7C00), below that the nearest half (65504 = 0x7BFF at
+    most).  A mirror-like band whose normals point along the half vector of sun and view produces such pixels; K5's target must hold
+    exactly the oracle's converted bits there (and be within one ulp everywhere else)."""
+    import pbrhip, pbr_oracle as O
+    W, H = 128, 72
+    gbd, env_tex, maps, gb, lp, glob = _shade_setup(gpu, W, H, pbrhip.Format_RGBA16F)
+    # per pixel: N = normalize(L + V) quantised to bytes, roughness 13/255, white dielectric, depth of a plane in front of the camera
+    g32 = np.frombuffer(bytes(glob), np.float32)
+    wfc = g32[32:48].reshape(4, 4).T.astype(np.float64)
+    sun = g32[128:131].astype(np.float64); cam = g32[132:135].astype(np.float64)
+    ys, xs = np.mgrid[0:H, 0:W]
+    depth = np.full((H, W), 0.9990, np.float32)
+    ndc = np.stack([(xs + 0.5) / W * 2 - 1, (ys + 0.5) / H * 2 - 1, depth.astype(np.float64), np.ones((H, W))], -1)
+    pw = ndc @ wfc.T
+    P = pw[..., :3] / pw[..., 3:]
+    V = cam - P; V /= np.linalg.norm(V, axis=-1, keepdims=True)
+    Hh = V - sun; Hh /= np.linalg.norm(Hh, axis=-1, keepdims=True)
+    nrm = np.zeros((H, W, 4), np.uint8); nrm[..., :3] = np.clip(np.rint((Hh * 0.5 + 0.5) * 255), 0, 255); nrm[..., 3] = 255
+    orm = np.zeros((H, W, 4), np.uint8); orm[..., 0] = 255; orm[..., 1] = 13; orm[H // 2:, :, 1] = 40
+    base = np.full((H, W, 4), 255, np.uint8); emi = np.zeros((H, W, 4), np.uint8)
+    gbd = dict(gbd, base=base, normal=nrm, orm=orm, emissive=emi, depth=depth)
+    for name, key in (("base_color", "base"), ("normal", "normal"), ("orm", "orm"), ("emissive", "emissive"), ("depth", "depth")):
+        pbrhip.upload_mip(getattr(gb, name), 0, gbd[key])
+    g = gpu.GPU_MakeGraph()
+    gpu.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
+    gpu.GPU_GraphSubmit(g); gpu.GPU_GraphWait(g)
+    got = pbrhip.read_mip(gb.lighting_result, 0).view(np.uint16).astype(np.int32)
+    want = _oracle_shade(gpu, gbd, maps, glob, O.SHADE_IBL)
+    wb = O.f32_to_f16_bits(want.astype(np.float32)).astype(np.int32)            # the oracle's own conversion (== numpy's RTE, inf from 65520 on)
+    over = want[..., :3] >= 65520.0 * (1.0 + 2e-4)
+    assert over.sum() > 50 and (want[..., :3] < 60000.0).sum() > 50, (int(over.sum()), float(want[..., :3].max()))
+    assert (got[..., :3][over] == 0x7C00).all()
+    assert np.abs(got[..., :3] - wb[..., :3]).max() <= 1
+    assert (got[..., 3] == 0x3C00).all()
+    gpu.GPU_DestroyGraph(g); gpu.PBR_DestroyLightingPass(lp); gpu.PBR_DestroyGBuffer(C.byref(gb))
+    gpu.PBR_DestroyIBLMaps(C.byref(maps)); gpu.GPU_DestroyTexture(env_tex)
+
+
 def test_lighting_tile_vs_oracle_a(gpu, golden_dir):
     """K5 through the low-level kernel ABI on the Oracle-A lighting tile is covered on CPU for the oracle;
     here: the sharded draw (GPUX_OpDrawRows) equals the full draw."""

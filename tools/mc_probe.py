@@ -62,7 +62,10 @@ def main():
         fl = (C.c_uint64 * 3)()
         if L.pbrk_mc_region_flag_stats(fl) == 0 and fl[1]:
             tiles = fl[1] // n_tab
-            print(f"   binning: {fl[0] / fl[1]:.3f} regions flagged per sample, {fl[2] / tiles:.2f} regions visited per tile ({tiles} tile launches)", flush=True)
+            wn = (C.c_uint64 * 1)()
+            L.pbrk_mc_region_window_stats(wn)
+            print(f"   binning: {fl[0] / fl[1]:.3f} regions flagged per sample, {fl[2] / tiles:.2f} regions visited per tile ({tiles} tile launches), "
+                  f"{wn[0] / fl[1]:.3f} of the samples proved in-region for the whole tile (test-free body)", flush=True)
         if L.pbrk_mc_region_stats(st, 1) == 0:
             print(f"   region kernel: {st[0]} of {st[1]} wave-slices recomputed with direct loads", flush=True)
     L.GPU_WaitUntilIdle(); L.GPU_Deinit()
