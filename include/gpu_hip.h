@@ -301,7 +301,7 @@ GPU_API void GPU_OpBindIndexBuffer(GPU_Graph* graph, GPU_Buffer* buffer);       
 GPU_API void GPU_OpCopyBufferToBuffer(GPU_Graph* graph, GPU_Buffer* src, GPU_Buffer* dst, uint32_t dst_offset, uint32_t src_offset, uint32_t size);   /* [gpu.h:491] */
 GPU_API void GPU_OpCopyBufferToTexture(GPU_Graph* graph, GPU_Buffer* src, GPU_Texture* dst, uint32_t dst_first_layer, uint32_t dst_layer_count, uint32_t dst_mip_level);   /* [gpu.h:492] */
 GPU_API void GPU_OpCopyTextureToBuffer(GPU_Graph* graph, GPU_Texture* src, GPU_Buffer* dst);   /* [gpu.h:493] mip 0, all layers (gpu_vulkan.c:2945-2951) */
-GPU_API void GPU_OpBlit(GPU_Graph* graph, const GPU_OpBlitInfo* info);               /* [gpu.h:495] exact 2:1 linear or 1:1 only */
+GPU_API void GPU_OpBlit(GPU_Graph* graph, const GPU_OpBlitInfo* info);               /* [gpu.h:495] whole 2-D subresources: 1:1 copy, 2:1 box, any other size = linear resample (RGBA32F) */
 GPU_API void GPU_OpGenerateMipmaps(GPU_Graph* graph, GPU_Texture* texture);          /* [gpu.h:496] */
 GPU_API void GPU_OpClearColorF(GPU_Graph* graph, GPU_Texture* dst, uint32_t mip_level, float r, float g, float b, float a);   /* [gpu.h:502] */
 GPU_API void GPU_OpClearColorI(GPU_Graph* graph, GPU_Texture* dst, uint32_t mip_level, uint32_t r, uint32_t g, uint32_t b, uint32_t a);   /* [gpu.h:503] */

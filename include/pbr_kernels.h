@@ -71,6 +71,9 @@ int    pbrk_host_irradiance_table(int nsamples, float* table4);
 int pbrk_mip_chain(void* pyramid, int W, int levels, void* stream);
 /* one exact 2:1 linear blit (GPU_OpBlit, gpu_vulkan.c:2786-2826) of `nlayers` square RGBA32F layers of size ns */
 int pbrk_box_downsample(const void* src, int ns, void* dst, int nlayers, void* stream);
+/* linear blit between whole RGBA32F subresources of any two sizes (all `nlayers` layers): the resample an odd mip level and a
+ * non-2:1 GPU_OpBlit need (vkCmdBlitImage, unnormalised linear filter, clamp to edge; rule stated in oracle/pbr_oracle.c A2) */
+int pbrk_blit_linear(const void* src, int ns_w, int ns_h, void* dst, int nd_w, int nd_h, int nlayers, void* stream);
 
 /* ---- border build: pyramid -> bordered pyramid (seamless-cube apron; sampler state of
  *      src/gpu/gpu_vulkan.c:613-634 applied to a cube view). */

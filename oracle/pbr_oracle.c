@@ -219,7 +219,15 @@ int orc_rgbe_decode(const uint8_t* bytes, size_t n, int* w, int* h, float* out) 
 
 /* ------------------------------------------------------------------------------------------ */
 /* A2: mip pyramid.  Count: src/gpu/gpu_vulkan.c:1344-1351.  Chain: :1458-1483 issues one      */
-/* linear vkCmdBlitImage per (level, face) at exact 2:1 (:2786-2826) => 2x2 box mean per face. */
+/* linear vkCmdBlitImage per (level, face) from the whole level l-1 (n x n) into the whole     */
+/* level l (floor(n/2) x floor(n/2)), :2786-2826.  Exact 2:1 (n even) => 2x2 box mean per face.*/
+/* n odd (faces that are not a power of two: asset_import.cpp:21 only asserts y == 6x): the    */
+/* blit is a genuine linear resample with scale n / floor(n/2).  The reference leaves its      */
+/* arithmetic to the driver (UNPINNED, like the box rule); defined here after the Vulkan spec  */
+/* (vkCmdBlitImage, unnormalised linear filtering, clamp to edge), in fp32, every op rounded:  */
+/*   u = (x + 0.5) * (ns / nd);  t = u - 0.5;  i0 = floor(t);  a = t - i0;  taps i0, i0 + 1    */
+/*   clamped to [0, ns - 1];  same along y with weight b;                                       */
+/*   out = (t00 (1 - a) + t10 a) (1 - b) + (t01 (1 - a) + t11 a) b                              */
 /* ------------------------------------------------------------------------------------------ */
 int orc_mip_count(int w, int h) {
     int s = w < h ? w : h, c = 1;
@@ -234,12 +242,42 @@ size_t orc_level_offset(int W, int level) {
 }
 size_t orc_pyramid_floats(int W) { return orc_level_offset(W, orc_mip_count(W, W)); }
 
+/* one linear blit of all layers: src [layers][ns_h][ns_w][4] -> dst [layers][nd_h][nd_w][4] (whole subresources) */
+void orc_blit_linear(const float* src, int ns_w, int ns_h, float* dst, int nd_w, int nd_h, int layers) {
+    const float sx = (float)ns_w / (float)nd_w, sy = (float)ns_h / (float)nd_h;
+    #pragma omp parallel for collapse(2) num_threads(ORC_NT()) if ((long)nd_w * nd_h >= 4096)
+    for (int f = 0; f < layers; ++f)
+        for (int y = 0; y < nd_h; ++y) {
+            const float tv = ((float)y + 0.5f) * sy - 0.5f;
+            const float fv = floorf(tv), b = tv - fv;
+            int j0 = (int)fv, j1 = j0 + 1;
+            j0 = j0 < 0 ? 0 : (j0 > ns_h - 1 ? ns_h - 1 : j0); j1 = j1 < 0 ? 0 : (j1 > ns_h - 1 ? ns_h - 1 : j1);
+            for (int x = 0; x < nd_w; ++x) {
+                const float tu = ((float)x + 0.5f) * sx - 0.5f;
+                const float fu = floorf(tu), a = tu - fu;
+                int i0 = (int)fu, i1 = i0 + 1;
+                i0 = i0 < 0 ? 0 : (i0 > ns_w - 1 ? ns_w - 1 : i0); i1 = i1 < 0 ? 0 : (i1 > ns_w - 1 ? ns_w - 1 : i1);
+                const float* t00 = src + (((size_t)f * ns_h + j0) * ns_w + i0) * 4;
+                const float* t10 = src + (((size_t)f * ns_h + j0) * ns_w + i1) * 4;
+                const float* t01 = src + (((size_t)f * ns_h + j1) * ns_w + i0) * 4;
+                const float* t11 = src + (((size_t)f * ns_h + j1) * ns_w + i1) * 4;
+                float* o = dst + (((size_t)f * nd_h + y) * nd_w + x) * 4;
+                for (int k = 0; k < 4; ++k) {
+                    const float top = t00[k] * (1.0f - a) + t10[k] * a;
+                    const float bot = t01[k] * (1.0f - a) + t11[k] * a;
+                    o[k] = top * (1.0f - b) + bot * b;
+                }
+            }
+        }
+}
+
 void orc_build_pyramid(float* pyr, int W) {
     int levels = orc_mip_count(W, W);
     for (int l = 1; l < levels; ++l) {
         int ns = level_size(W, l - 1), nd = level_size(W, l);
         const float* src = pyr + orc_level_offset(W, l - 1);
         float* dst = pyr + orc_level_offset(W, l);
+        if (ns != 2 * nd) { orc_blit_linear(src, ns, ns, dst, nd, nd, 6); continue; }      /* odd level: genuine linear resample */
         #pragma omp parallel for collapse(2) num_threads(ORC_NT()) if (nd >= 64)
         for (int f = 0; f < 6; ++f)
             for (int y = 0; y < nd; ++y)

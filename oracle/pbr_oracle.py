@@ -87,6 +87,7 @@ def lib():
     L.orc_pyramid_floats.argtypes = [C.c_int]
     L.orc_pyramid_floats.restype = C.c_size_t
     L.orc_build_pyramid.argtypes = [f32p, C.c_int]
+    L.orc_blit_linear.argtypes = [f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_int]
     L.orc_face_dir.argtypes = [C.c_int, C.c_float, C.c_float, f32p]
     L.orc_cube_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, C.c_float, f32p]
     L.orc_cube_neighbor.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -169,6 +170,15 @@ def build_pyramid(level0):
     pyr[: level0.size] = level0.ravel()
     lib().orc_build_pyramid(pyr, W)
     return pyr
+
+
+def blit_linear(src, nd_w, nd_h):
+    """src: float32 [layers][h][w][4] -> [layers][nd_h][nd_w][4], the linear-blit rule of pbr_oracle.c A2."""
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    layers, h, w, _ = src.shape
+    out = np.zeros((layers, nd_h, nd_w, 4), np.float32)
+    lib().orc_blit_linear(src, w, h, out, nd_w, nd_h, layers)
+    return out
 
 
 def pyramid_level(pyr, W, level):

@@ -44,6 +44,78 @@ def test_mip_chain_bit_exact(gpu, env64):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"level {m}"
 
 
+@pytest.mark.parametrize("W", [96, 1000])
+def test_mip_chain_of_faces_that_are_not_a_power_of_two(gpu, W):
+    """the reference builds 1 + floor(log2 W) levels of max(1, W >> l) texels by linear blits for ANY face size
+    (gpu_vulkan.c:1344-1351, 1458-1483, 2786-2826; asset_import.cpp:21 only asserts y == 6x).  W = 96: 96, 48, 24, 12, 6, 3, 1 (the
+    last level resamples an odd source); W = 1000: 1000, 500, 250, 125, 62, 31, 15, 7, 3, 1 (five odd sources).  Even steps are the
+    2x2 box, odd ones the linear resample stated in oracle/pbr_oracle.c A2; GPU == oracle bit for bit on every level, through the
+    uploading GPU_MakeTexture, through GPU_OpGenerateMipmaps and through explicit GPU_OpBlit calls, as the reference issues them."""
+    import pbrhip, pbr_oracle as O
+    from pbrhip import synth
+    L = gpu
+    env = synth.synth_env(W, seed=0x5EED00B0 + W, workers=1)
+    pyr = O.build_pyramid(env)
+    levels = O.mip_count(W)
+    assert levels == 1 + int(np.floor(np.log2(W)))
+    tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, W, W, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)     # upload + chain
+    assert tex.contents.mip_level_count == levels
+    for m in range(levels):
+        got = pbrhip.read_mip(tex, m)
+        want = O.pyramid_level(pyr, W, m)
+        assert got.shape == want.shape == (6, max(1, W >> m), max(1, W >> m), 4)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"upload path, level {m}"
+    g = L.GPU_MakeGraph()
+    for m in range(1, levels):
+        L.GPU_OpClearColorF(g, tex, m, 0.0, 0.0, 0.0, 0.0)
+    L.GPU_OpGenerateMipmaps(g, tex)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    for m in range(levels):
+        assert np.array_equal(pbrhip.read_mip(tex, m).view(np.uint32), O.pyramid_level(pyr, W, m).view(np.uint32)), f"GPU_OpGenerateMipmaps, level {m}"
+    if W <= 128:                                    # the reference's own loop: one blit per (level, face)
+        class Off(C.Structure):
+            _fields_ = [("x", C.c_int), ("y", C.c_int), ("z", C.c_int)]
+
+        class Blit(C.Structure):                    # GPU_OpBlitInfo [gpu.h:317-327]
+            _fields_ = [("filter", C.c_int), ("src_texture", pbrhip.TexP), ("dst_texture", pbrhip.TexP), ("src_layer", C.c_uint32), ("dst_layer", C.c_uint32),
+                        ("src_mip_level", C.c_uint32), ("dst_mip_level", C.c_uint32), ("src_area", Off * 2), ("dst_area", Off * 2)]
+        for m in range(1, levels):
+            L.GPU_OpClearColorF(g, tex, m, 0.0, 0.0, 0.0, 0.0)
+        sw = W
+        for m in range(1, levels):
+            for layer in range(6):
+                b = Blit(); b.filter = 0; b.src_texture = tex; b.src_mip_level = m - 1; b.src_layer = layer; b.dst_texture = tex; b.dst_mip_level = m; b.dst_layer = layer
+                b.src_area[1] = Off(sw, sw, 1); b.dst_area[1] = Off(sw // 2, sw // 2, 1)
+                L.GPU_OpBlit(g, C.byref(b))
+            sw //= 2
+        L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+        for m in range(levels):
+            assert np.array_equal(pbrhip.read_mip(tex, m).view(np.uint32), O.pyramid_level(pyr, W, m).view(np.uint32)), f"GPU_OpBlit chain, level {m}"
+    L.GPU_DestroyGraph(g); L.GPU_DestroyTexture(tex)
+
+
+def test_precompute_from_an_environment_that_is_not_a_power_of_two(gpu):
+    """The whole precompute from a 96^2 HDR cube (levels 96 .. 1): K4a copies from the 48^2 level, K4b filters the 12^2, 6^2, 3^2
+    levels, K3 the 1^2 level -- source sizes none of the power-of-two tests reach -- vs the oracle at 1e-4."""
+    import pbrhip, pbr_oracle as O
+    from pbrhip import synth
+    L = gpu
+    W = 96
+    env = synth.synth_env(W, seed=0x5EED00B7, workers=1)
+    pyr = O.build_pyramid(env)
+    tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, W, W, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+    spec = _run_prefilter(L, tex, 64, 1)
+    for m in range(7):
+        got = pbrhip.read_mip(spec, m)
+        want = O.prefilter_mip(pyr, W, 64, m)
+        assert rel_err(got, want, floor=1e-3) < REL, f"mip {m}: {rel_err(got, want, floor=1e-3)}"
+    irr = pbrhip.make_texture(pbrhip.Format_RGBA32F, 16, 16, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_StorageImage)
+    L.PBR_GenIrradianceMap(tex, irr)
+    want = O.irradiance(pyr, W, 16)
+    assert rel_err(pbrhip.read_mip(irr, 0)[..., :3], want[..., :3], floor=1e-3) < REL
+    L.GPU_DestroyTexture(irr); L.GPU_DestroyTexture(spec); L.GPU_DestroyTexture(tex)
+
+
 def test_brdf_lut_fp32_and_fp16(gpu, golden_dir):
     """K1 vs the Oracle-A LUT (reference shader text executed on the CPU)."""
     import pbrhip, pbr_oracle as O

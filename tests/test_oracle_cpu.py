@@ -273,3 +273,42 @@ def test_full_live_lighting_with_voxel_gi(O, golden_dir, meta):
     assert max(abs(L.orc_cosf_det(float(x)) - np.cos(np.float64(x))) for x in xs) < 2e-7
     xa = np.linspace(0, 1, 2001).astype(np.float32)
     assert max(abs(L.orc_acosf_det(float(x)) - np.arccos(np.float64(x))) for x in xa) < 3e-7
+
+
+def test_linear_blit_rule_for_levels_that_are_not_2_to_1():
+    """oracle/pbr_oracle.c A2: mip levels of faces that are not a power of two (125 -> 62, 3 -> 1) are genuine linear resamples
+    (vkCmdBlitImage: u = (x + .5) ns / nd, taps floor(u - .5) and + 1 clamped to the edge, weights in fp32).  The C loop against a
+    numpy restatement of the same operations in float32 (bit for bit), the level sizes of the reference (gpu_vulkan.c:1344-1351),
+    and the properties the rule must have: constants are preserved, 3 -> 1 returns the centre texel, an exact 2:1 resample agrees
+    with the 2x2 box to an ulp."""
+    import pbr_oracle as O
+    rng = np.random.default_rng(0x5EED00C1)
+    f32 = np.float32
+    for (ns, nd) in ((125, 62), (31, 15), (7, 3), (3, 1), (10, 4)):
+        src = (rng.random((2, ns, ns, 4), dtype=np.float32) * 50.0).astype(np.float32)
+        got = O.blit_linear(src, nd, nd)
+        sc = f32(ns) / f32(nd)
+        t = (np.arange(nd, dtype=np.float32) + f32(0.5)) * sc - f32(0.5)
+        fl = np.floor(t)
+        a = (t - fl).astype(np.float32)
+        i0 = np.clip(fl.astype(np.int64), 0, ns - 1); i1 = np.clip(fl.astype(np.int64) + 1, 0, ns - 1)
+        ax = a[None, None, :, None]; ay = a[None, :, None, None]
+        one = f32(1.0)
+        top = src[:, i0][:, :, i0] * (one - ax) + src[:, i0][:, :, i1] * ax
+        bot = src[:, i1][:, :, i0] * (one - ax) + src[:, i1][:, :, i1] * ax
+        want = (top * (one - ay) + bot * ay).astype(np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (ns, nd)
+    c = np.full((1, 9, 9, 4), 3.25, np.float32)
+    assert (O.blit_linear(c, 4, 4) == 3.25).all()
+    s3 = rng.random((1, 3, 3, 4), dtype=np.float32)
+    assert np.array_equal(O.blit_linear(s3, 1, 1)[0, 0, 0], s3[0, 1, 1])
+    s8 = rng.random((1, 8, 8, 4), dtype=np.float32)
+    box = s8.reshape(1, 4, 2, 4, 2, 4).astype(np.float64).mean(axis=(2, 4))
+    assert np.abs(O.blit_linear(s8, 4, 4) - box).max() <= 2.0 ** -23
+    for W in (96, 1000, 125, 1536):
+        n = O.mip_count(W)
+        assert n == 1 + int(np.floor(np.log2(W)))
+    env = rng.random((6, 12, 12, 4), dtype=np.float32)              # 12, 6, 3, 1: box, box, resample
+    pyr = O.build_pyramid(env)
+    l2 = O.pyramid_level(pyr, 12, 2); l3 = O.pyramid_level(pyr, 12, 3)
+    assert l3.shape == (6, 1, 1, 4) and np.array_equal(l3[:, 0, 0], l2[:, 1, 1])

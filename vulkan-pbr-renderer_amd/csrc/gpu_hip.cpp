@@ -409,8 +409,8 @@ static GPU_Texture* make_texture_impl(GPU_Format format, uint32_t width, uint32_
     if (data) {
         HIP_OK(hipMemcpy(t->dev, data, (size_t)GPUX_TextureMipBytes(&t->base, 0), hipMemcpyHostToDevice));
         if (mips > 1) {                                                        // gpu_vulkan.c:1444-1446
-            if (!is_f4_cube(t) || (width & (width - 1))) {
-                gpu_fail("%s: mip generation is implemented for power-of-two RGBA32F cubemaps only", fn);
+            if (!is_f4_cube(t)) {
+                gpu_fail("%s: mip generation is implemented for RGBA32F cubemaps only", fn);
             } else {
                 int rc = pbrk_mip_chain(t->dev, (int)width, (int)mips, nullptr);
                 if (rc != PBRK_OK) gpu_fail("%s: mip chain kernel failed (%d)", fn, rc);
@@ -431,7 +431,6 @@ GPU_API GPU_Texture* GPUX_MakeTextureExternal(GPU_Format format, uint32_t width,
 }
 GPU_API GPU_Texture* GPUX_MakeCubemapFromEquirect(const void* rgba32f, uint32_t width, uint32_t height, uint32_t face_size, GPU_TextureFlags extra_flags) {
     GPU_REQUIRE(rgba32f && width > 0 && height > 0 && face_size > 0, nullptr, "GPUX_MakeCubemapFromEquirect: bad arguments");
-    GPU_REQUIRE(!(face_size & (face_size - 1)), nullptr, "GPUX_MakeCubemapFromEquirect: face_size must be a power of two (mip chain)");
     GPU_Texture* tex = make_texture_impl(GPU_Format_RGBA32F, face_size, face_size, 1, GPU_TextureFlag_Cubemap | GPU_TextureFlag_HasMipmaps | extra_flags,
                                          nullptr, nullptr, 0, __func__);
     if (!tex) return nullptr;
@@ -1065,7 +1064,7 @@ GPU_API void GPU_OpGenerateMipmaps(GPU_Graph* g, GPU_Texture* tex) {
     REC_GUARD(g);
     GPU_REQUIRE_V(tex, "GPU_OpGenerateMipmaps: NULL texture");
     TextureImpl* t = (TextureImpl*)tex;
-    GPU_REQUIRE_V(is_f4_cube(t) && !(tex->width & (tex->width - 1)), "GPU_OpGenerateMipmaps: implemented for power-of-two RGBA32F cubemaps only");
+    GPU_REQUIRE_V(is_f4_cube(t), "GPU_OpGenerateMipmaps: implemented for RGBA32F cubemaps only");
     Op op; op.kind = Op_MipGen; op.name = "K2.mip_chain"; op.tex = t;
     g->ops.push_back(op);
 }
@@ -1098,8 +1097,11 @@ GPU_API void GPU_OpBlit(GPU_Graph* g, const GPU_OpBlitInfo* info) {
     uint32_t dw = mip_dim(d->width, info->dst_mip_level), dh = mip_dim(d->height, info->dst_mip_level);
     bool full = info->src_area[0].x == 0 && info->src_area[0].y == 0 && info->dst_area[0].x == 0 && info->dst_area[0].y == 0 &&
                 (uint32_t)info->src_area[1].x == sw && (uint32_t)info->src_area[1].y == sh && (uint32_t)info->dst_area[1].x == dw && (uint32_t)info->dst_area[1].y == dh;
-    GPU_REQUIRE_V(full && sw == sh && dw == dh && sw == 2 * dw, "GPU_OpBlit: only whole-subresource exact 2:1 square blits are implemented");
-    Op op; op.kind = Op_Blit; op.name = "K2.blit_2to1";
+    GPU_REQUIRE_V(full && s->depth == 1 && d->depth == 1, "GPU_OpBlit: only whole-subresource 2-D blits are implemented");
+    Op op; op.kind = Op_Blit;
+    // exact 2:1 square blits (every level of a power-of-two mip chain, gpu_vulkan.c:1458-1483) are the 2x2 box; anything else is the
+    // linear resample of oracle/pbr_oracle.c A2 (odd levels of faces that are not a power of two: 125 -> 62)
+    op.name = (sw == sh && dw == dh && sw == 2 * dw) ? "K2.blit_2to1" : "K2.blit_linear";
     op.tex = (TextureImpl*)s; op.tex2 = (TextureImpl*)d; op.mip = info->src_mip_level; op.mip2 = info->dst_mip_level;
     op.layer0 = info->src_layer; op.layer2 = info->dst_layer;
     g->ops.push_back(op);
@@ -1436,12 +1438,14 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
             op.tex2->bordered_valid = false; op.tex2->lut_cells_valid = false;
             return;
         }
-        uint32_t ns = mip_dim(op.tex->base.width, op.mip);
-        size_t layer_bytes_s = (size_t)ns * ns * 16, layer_bytes_d = layer_bytes_s / 4;
+        uint32_t nsw = mip_dim(op.tex->base.width, op.mip), nsh = mip_dim(op.tex->base.height, op.mip);
+        uint32_t ndw = mip_dim(op.tex2->base.width, op.mip2), ndh = mip_dim(op.tex2->base.height, op.mip2);
+        size_t layer_bytes_s = (size_t)nsw * nsh * 16, layer_bytes_d = (size_t)ndw * ndh * 16;
         const void* src = (const char*)op.tex->dev + op.tex->mip_offset[op.mip] + layer_bytes_s * op.layer0;
         void* dst = (char*)op.tex2->dev + op.tex2->mip_offset[op.mip2] + layer_bytes_d * op.layer2;
         timed(g, op.name, ev_used, [&] {
-            int rc = pbrk_box_downsample(src, (int)ns, dst, 1, st);
+            int rc = (nsw == nsh && ndw == ndh && nsw == 2 * ndw) ? pbrk_box_downsample(src, (int)nsw, dst, 1, st)
+                                                                  : pbrk_blit_linear(src, (int)nsw, (int)nsh, dst, (int)ndw, (int)ndh, 1, st);
             if (rc != PBRK_OK) gpu_fail("blit launch failed (%d)", rc);
         });
         op.tex2->bordered_valid = false;

@@ -60,6 +60,32 @@ __global__ __launch_bounds__(256) void k_mip_level2(const float4* __restrict__ s
     dst2[((size_t)f * n2 + y2) * n2 + x2] = box4(r[0], r[1], r[2], r[3]);
 }
 
+// K2 for levels that are not an exact 2:1 of their source (faces that are not a power of two: 125 -> 62, 3 -> 1), and
+// GPU_OpBlit between whole RGBA32F subresources of any two sizes: a genuine linear resample, the rule of oracle/pbr_oracle.c A2
+// (vkCmdBlitImage, unnormalised linear filtering, clamp to edge; fp32, every operation rounded -- the file is compiled with
+// -ffp-contract=off).  The scales ns / nd are formed on the host by a correctly rounded division.
+__global__ __launch_bounds__(256) void k_blit_linear(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                     int ns_w, int ns_h, int nd_w, int nd_h, float sx, float sy) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int f = blockIdx.z;
+    if (x >= nd_w || y >= nd_h) return;
+    const float tu = ((float)x + 0.5f) * sx - 0.5f, tv = ((float)y + 0.5f) * sy - 0.5f;
+    const float fu = floorf(tu), fv = floorf(tv);
+    const float a = tu - fu, b = tv - fv;
+    const int i0 = min(max((int)fu, 0), ns_w - 1), i1 = min(max((int)fu + 1, 0), ns_w - 1);
+    const int j0 = min(max((int)fv, 0), ns_h - 1), j1 = min(max((int)fv + 1, 0), ns_h - 1);
+    const float4* p = src + (size_t)f * ns_h * ns_w;
+    const float4 t00 = p[(size_t)j0 * ns_w + i0], t10 = p[(size_t)j0 * ns_w + i1], t01 = p[(size_t)j1 * ns_w + i0], t11 = p[(size_t)j1 * ns_w + i1];
+    const float ia = 1.0f - a, ib = 1.0f - b;
+    float4 o;
+    o.x = (t00.x * ia + t10.x * a) * ib + (t01.x * ia + t11.x * a) * b;
+    o.y = (t00.y * ia + t10.y * a) * ib + (t01.y * ia + t11.y * a) * b;
+    o.z = (t00.z * ia + t10.z * a) * ib + (t01.z * ia + t11.z * a) * b;
+    o.w = (t00.w * ia + t10.w * a) * ib + (t01.w * ia + t11.w * a) * b;
+    dst[((size_t)f * nd_h + y) * nd_w + x] = o;
+}
+
 // ------------------------------------------------------------------------------------------
 // Apron build.  Edge adjacency of the Vulkan cube faces (table in gen_prefiltered_env_map.glsl:12-23),
 // per face and edge {left i=-1, right i=n, top j=-1, bottom j=n}: neighbour face and how its
@@ -194,21 +220,37 @@ static inline int grid_for(size_t total, int block, int cap) {
 }
 static inline int lvl_size(int W, int l) { int n = W >> l; return n < 1 ? 1 : n; }
 
+extern "C" int pbrk_blit_linear(const void* src, int ns_w, int ns_h, void* dst, int nd_w, int nd_h, int nlayers, void* stream) {
+    if (!src || !dst || ns_w < 1 || ns_h < 1 || nd_w < 1 || nd_h < 1 || nlayers < 1) return PBRK_E_ARG;
+    hipLaunchKernelGGL(k_blit_linear, dim3((nd_w + 63) / 64, (nd_h + 3) / 4, nlayers), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)src, (float4*)dst, ns_w, ns_h, nd_w, nd_h, (float)ns_w / (float)nd_w, (float)ns_h / (float)nd_h);
+    return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+}
+
+// Level sizes are the reference's (gpu_vulkan.c:1344-1351, 1458-1483): n_l = max(1, W >> l), as many levels as 1 + floor(log2 W).
+// A level that is exactly half its source takes the 2x2 box kernels (two levels per launch while that holds for both); an odd
+// source (faces that are not a power of two) takes the linear resample.
 extern "C" int pbrk_mip_chain(void* pyramid, int W, int levels, void* stream) {
     if (!pyramid || W <= 0 || levels < 1 || levels > pbrk_mip_count(W, W)) return PBRK_E_ARG;
-    if (W & (W - 1)) return PBRK_E_ARG;    // exact 2:1 chain only
     float4* base = (float4*)pyramid;
+    auto even = [&](int l) { return lvl_size(W, l - 1) == 2 * lvl_size(W, l); };      // level l is an exact 2:1 of level l - 1
     int l = 1;
-    for (; l + 1 < levels && lvl_size(W, l + 1) >= 2; l += 2) {              // pairs of levels while the second one is at least 2x2
-        int ns = lvl_size(W, l - 1), n1 = lvl_size(W, l), n2 = lvl_size(W, l + 1);
-        hipLaunchKernelGGL(k_mip_level2, dim3((n2 + 63) / 64, (n2 + 3) / 4, 6), dim3(256), 0, (hipStream_t)stream,
-                           (const float4*)(base + pbrk_level_offset(W, l - 1)), base + pbrk_level_offset(W, l), base + pbrk_level_offset(W, l + 1), ns, n1, n2);
-    }
-    for (; l < levels; ++l) {
-        int ns = lvl_size(W, l - 1), nd = lvl_size(W, l);
+    while (l < levels) {
+        int ns = lvl_size(W, l - 1), n1 = lvl_size(W, l);
         const float4* src = base + pbrk_level_offset(W, l - 1);
-        float4* dst = base + pbrk_level_offset(W, l);
-        hipLaunchKernelGGL(k_mip_level, dim3((nd + 63) / 64, (nd + 3) / 4, 6), dim3(256), 0, (hipStream_t)stream, src, dst, ns, nd, 6);
+        if (l + 1 < levels && even(l) && even(l + 1) && lvl_size(W, l + 1) >= 2) {      // pairs of levels while the second one is at least 2x2
+            int n2 = lvl_size(W, l + 1);
+            hipLaunchKernelGGL(k_mip_level2, dim3((n2 + 63) / 64, (n2 + 3) / 4, 6), dim3(256), 0, (hipStream_t)stream,
+                               src, base + pbrk_level_offset(W, l), base + pbrk_level_offset(W, l + 1), ns, n1, n2);
+            l += 2;
+        } else if (even(l)) {
+            hipLaunchKernelGGL(k_mip_level, dim3((n1 + 63) / 64, (n1 + 3) / 4, 6), dim3(256), 0, (hipStream_t)stream, src, base + pbrk_level_offset(W, l), ns, n1, 6);
+            l += 1;
+        } else {
+            hipLaunchKernelGGL(k_blit_linear, dim3((n1 + 63) / 64, (n1 + 3) / 4, 6), dim3(256), 0, (hipStream_t)stream,
+                               src, base + pbrk_level_offset(W, l), ns, ns, n1, n1, (float)ns / (float)n1, (float)ns / (float)n1);
+            l += 1;
+        }
     }
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
