@@ -69,6 +69,12 @@ int    pbrk_host_irradiance_table(int nsamples, float* table4);
 /* ---- K2: mip chain, replaces GPU_OpGenerateMipmaps' per-(level,face) linear blits
  *      (src/gpu/gpu_vulkan.c:1458-1483, :2786-2826): level l = 2x2 box mean of level l-1, per face. */
 int pbrk_mip_chain(void* pyramid, int W, int levels, void* stream);
+/* Cube-sampler convention (the reference leaves it to the driver, gpu_vulkan.c:613-634).  0 (default): exact fp32
+ * tap weights.  1: texel coordinates and the LOD fraction snapped to 1/256, the sub-texel / mip-fraction resolution of real
+ * texture units and of this repo's 2-D / 3-D samplers.  With 1, K3 / K4a / K4b / K5 run their general kernels (the fast ones
+ * implement the default only): a switch to measure how far the outputs move between the two, not a production mode. */
+void pbrk_set_cube_sampler_snap(int on);
+int pbrk_get_cube_sampler_snap(void);
 /* one exact 2:1 linear blit (GPU_OpBlit, gpu_vulkan.c:2786-2826) of `nlayers` square RGBA32F layers of size ns */
 int pbrk_box_downsample(const void* src, int ns, void* dst, int nlayers, void* stream);
 /* linear blit between whole RGBA32F subresources of any two sizes (all `nlayers` layers): the resample an odd mip level and a

@@ -390,6 +390,16 @@ static void fetch_tap(const float* lvl, int n, int f, int i, int j, float out[4]
     for (int k = 0; k < 4; ++k) out[k] = ((a[k] + b[k]) + c[k]) / 3.0f;
 }
 
+/* Sampler-coordinate convention (UNPINNED: the reference defers to the driver, gpu_vulkan.c:613-634).  Default: exact fp32 tap
+ * weights.  orc_set_cube_sampler_snap(1): texel coordinates and the LOD fraction are first snapped to 1/256 -- the 8 sub-texel /
+ * mip-fraction bits real texture units resolve (Vulkan subTexelPrecisionBits / mipmapPrecisionBits), the convention the 2-D / 3-D
+ * samplers of the widened passes already use (snap_split).  Exists to MEASURE how far the outputs move between two conventions
+ * a conformant implementation may choose (tests/test_gpu_parity.py, bench.py --check). */
+static int g_cube_snap = 0;
+void orc_set_cube_sampler_snap(int on) { g_cube_snap = on != 0; }
+int orc_get_cube_sampler_snap(void) { return g_cube_snap; }
+static inline float snap256(float x) { return floorf(x * 256.0f + 0.5f) * (1.0f / 256.0f); }
+
 static void sample_level(const float* pyr, int W, int l, v3 d, float out[4]) {
     int n = level_size(W, l);
     const float* lvl = pyr + orc_level_offset(W, l);
@@ -399,6 +409,7 @@ static void sample_level(const float* pyr, int W, int l, v3 d, float out[4]) {
     float t = 0.5f * tc / ma + 0.5f;
     float u = s * (float)n - 0.5f;
     float v = t * (float)n - 0.5f;
+    if (g_cube_snap) { u = snap256(u); v = snap256(v); }
     float fu = floorf(u), fv = floorf(v);
     float a = u - fu, b = v - fv;
     int i0 = (int)fu, j0 = (int)fv;
@@ -427,6 +438,7 @@ static void cube_sample(const float* pyr, int W, int levels, v3 d, float lod, fl
     float maxl = (float)(levels - 1);
     if (lod < 0) lod = 0;
     if (lod > maxl) lod = maxl;
+    if (g_cube_snap) lod = snap256(lod);
     float fl = floorf(lod);
     int l0 = (int)fl;
     float w = lod - fl;

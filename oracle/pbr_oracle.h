@@ -62,6 +62,9 @@ int    orc_rgbe_decode(const uint8_t* bytes, size_t n, int* w, int* h, float* ou
 int    orc_mip_count(int w, int h);                 /* gpu_vulkan.c:1344-1351 */
 size_t orc_level_offset(int W, int level);          /* float offset of level in [level][face][y][x][4] */
 size_t orc_pyramid_floats(int W);
+/* cube sampler convention: 0 = exact fp32 tap weights (default), 1 = coordinates and LOD fraction snapped to 1/256 (see pbr_oracle.c) */
+void   orc_set_cube_sampler_snap(int on);
+int    orc_get_cube_sampler_snap(void);
 void   orc_build_pyramid(float* pyr, int W);        /* level 0 present; fills levels 1.. (gpu_vulkan.c:1458-1483) */
 /* one linear blit of whole subresources, all layers: the rule stated in pbr_oracle.c A2 (exact 2:1 blits of the chain use the box rule) */
 void   orc_blit_linear(const float* src, int ns_w, int ns_h, float* dst, int nd_w, int nd_h, int layers);

@@ -87,6 +87,7 @@ def lib():
     L.orc_pyramid_floats.argtypes = [C.c_int]
     L.orc_pyramid_floats.restype = C.c_size_t
     L.orc_build_pyramid.argtypes = [f32p, C.c_int]
+    L.orc_set_cube_sampler_snap.argtypes = [C.c_int]
     L.orc_blit_linear.argtypes = [f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_int]
     L.orc_face_dir.argtypes = [C.c_int, C.c_float, C.c_float, f32p]
     L.orc_cube_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, C.c_float, f32p]
@@ -170,6 +171,11 @@ def build_pyramid(level0):
     pyr[: level0.size] = level0.ravel()
     lib().orc_build_pyramid(pyr, W)
     return pyr
+
+
+def set_cube_sampler_snap(on):
+    """0: exact fp32 tap weights (default); 1: texel coordinates and LOD fraction snapped to 1/256 (pbr_oracle.c)."""
+    lib().orc_set_cube_sampler_snap(1 if on else 0)
 
 
 def blit_linear(src, nd_w, nd_h):

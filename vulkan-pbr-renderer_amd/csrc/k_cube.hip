@@ -200,16 +200,23 @@ __global__ __launch_bounds__(256) void k_prefilter_copy(const float4* __restrict
 // general sizes (not a power of two, or a level beyond the fp32 index range): the plain exact path
 __global__ __launch_bounds__(256) void k_prefilter_copy_general(const float4* __restrict__ src, int n_src,
                                                                 float4* __restrict__ out, int size,
-                                                                int face0, int y0, int rows) {
+                                                                int face0, int y0, int rows, int snap) {
     int x = blockIdx.x * 64 + (threadIdx.x & 63);
     int yr = blockIdx.y * 4 + (threadIdx.x >> 6);
     int f = face0 + blockIdx.z;
     if (x >= size || yr >= rows) return;
     int y = y0 + yr;
     f3 R = face_texel_dir(f, x, y, size);
-    float4 v = cube_fetch_rgba<true>(src, n_src, R);
+    float4 v = cube_fetch_rgba<true>(src, n_src, R, snap != 0);
     out[((size_t)f * size + y) * size + x] = v;
 }
+
+// Cube-sampler convention switch: 0 = exact fp32 tap weights (default, every fast kernel), 1 = coordinates and
+// LOD fraction snapped to 1/256 texel.  With the switch on, K3 / K4 / K5 run their general kernels (the fast ones implement the
+// default convention only): a diagnostic to MEASURE how far the outputs move between two conventions the reference permits.
+static int g_cube_snap = 0;
+extern "C" void pbrk_set_cube_sampler_snap(int on) { g_cube_snap = on != 0; }
+extern "C" int pbrk_get_cube_sampler_snap(void) { return g_cube_snap; }
 
 // ------------------------------------------------------------------------------------------
 static inline int grid_for(size_t total, int block, int cap) {
@@ -285,11 +292,12 @@ extern "C" int pbrk_prefilter_copy(const void* src_bordered_level, int n_src, vo
     if (face0 < 0 || face1 > 6 || face0 >= face1 || y0 < 0 || y1 > out_size || y0 >= y1) return PBRK_E_ARG;
     dim3 grid((out_size + 63) / 64, (y1 - y0 + 3) / 4, face1 - face0);
     size_t src_bytes = (size_t)6 * (n_src + 2) * (n_src + 2) * 16;
-    if ((out_size & (out_size - 1)) == 0 && n_src <= 1600)         // 6 (n + 2)^2 < 2^24: the texel index is exact in fp32
+    const int snap = pbrk_get_cube_sampler_snap();                 // diagnostic convention: general kernel only
+    if (!snap && (out_size & (out_size - 1)) == 0 && n_src <= 1600)         // 6 (n + 2)^2 < 2^24: the texel index is exact in fp32
         hipLaunchKernelGGL(k_prefilter_copy, grid, dim3(256), 0, (hipStream_t)stream,
                            (const float4*)src_bordered_level, n_src, (unsigned)src_bytes, (float4*)out, out_size, face0, y0, y1 - y0);
     else
         hipLaunchKernelGGL(k_prefilter_copy_general, grid, dim3(256), 0, (hipStream_t)stream,
-                           (const float4*)src_bordered_level, n_src, (float4*)out, out_size, face0, y0, y1 - y0);
+                           (const float4*)src_bordered_level, n_src, (float4*)out, out_size, face0, y0, y1 - y0, snap);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }

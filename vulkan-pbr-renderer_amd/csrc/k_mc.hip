@@ -22,7 +22,9 @@
 
 #include <stdlib.h>
 
-template <int S, int UNROLL, bool CELLS>
+// SNAP: the diagnostic cube-sampler convention (tap coordinates snapped to 1/256 texel, pbrk_set_cube_sampler_snap); a separate
+// instantiation, so that the default kernel's inner loop is untouched
+template <int S, int UNROLL, bool CELLS, bool SNAP = false>
 __global__ __launch_bounds__(256) void k_mc_filter(const McArgs p) {
     constexpr int TX = 256 / S;
     constexpr int TW = TX >= 16 ? 16 : TX;
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void k_mc_filter(const McArgs p) {
         L.x = fmaf(e.x, B.x, fmaf(e.y, T.x, e.z * R.x));
         L.y = fmaf(e.x, B.y, fmaf(e.y, T.y, e.z * R.y));
         L.z = fmaf(e.x, B.z, fmaf(e.y, T.z, e.z * R.z));
-        f3 c = sample_bordered<CELLS>(rs, L, nf, off, nb, row_bytes);
+        f3 c = sample_bordered<CELLS>(rs, L, nf, off, nb, row_bytes, SNAP);
         ar = fmaf(e.w, c.x, ar);
         ag = fmaf(e.w, c.y, ag);
         ab = fmaf(e.w, c.z, ab);
@@ -240,7 +242,8 @@ static void launch_mc(McArgs a, int nfaces, hipStream_t st) {
     int tiles_y = (a.rows + TH - 1) / TH;
     a.tiles_per_face = a.tiles_x * tiles_y;
     dim3 grid((unsigned)(a.tiles_per_face * nfaces));
-    if (a.cells) hipLaunchKernelGGL((k_mc_filter<S, 4, true>), grid, dim3(256), 0, st, a);
+    if (a.snap) hipLaunchKernelGGL((k_mc_filter<S, 4, false, true>), grid, dim3(256), 0, st, a);
+    else if (a.cells) hipLaunchKernelGGL((k_mc_filter<S, 4, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_mc_filter<S, 4, false>), grid, dim3(256), 0, st, a);
 }
 
@@ -286,9 +289,10 @@ extern "C" int pbrk_mc_filter(const void* src_bordered_level, const void* src_ce
     a.face0 = face0; a.y0 = y0; a.rows = y1 - y0;
     int nfaces = face1 - face0;
     hipStream_t st = (hipStream_t)stream;
+    a.snap = pbrk_get_cube_sampler_snap();                      // diagnostic convention: the direct kernel only
     // Kernel choice and the sample-split factor S depend on the LEVEL size only
-    if (launch_mc_region(a, nfaces, st)) return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
-    if (launch_mc_lds(a, nfaces, st)) return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+    if (!a.snap && launch_mc_region(a, nfaces, st)) return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+    if (!a.snap && launch_mc_lds(a, nfaces, st)) return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
     // Sample-split factor S depends on the LEVEL size only (not on the dispatched sub-range), so that a
     // sharded dispatch sums in exactly the same order as a full one (bit-identical results).
     size_t texels = (size_t)6 * out_size * out_size;

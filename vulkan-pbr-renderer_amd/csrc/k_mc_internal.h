@@ -10,6 +10,7 @@ struct McArgs {
     float divisor, alpha;
     float4* out; int size;
     int face0, y0, rows, tiles_x, tiles_per_face;
+    int snap;                                           // host side: cube-sampler convention (pbrk_set_cube_sampler_snap) -> the SNAP instantiation of the direct kernel
 };
 
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
@@ -34,7 +35,7 @@ __device__ __forceinline__ f3 fetch_cells(__amdgpu_buffer_rsrc_t rc, int voff, f
 
 // one sample: direction L -> bilinear RGB of the bordered level behind `rs`
 template <bool CELLS>
-__device__ __forceinline__ f3 sample_bordered(__amdgpu_buffer_rsrc_t rs, f3 L, float nf, float off, int nb, int row_bytes) {
+__device__ __forceinline__ f3 sample_bordered(__amdgpu_buffer_rsrc_t rs, f3 L, float nf, float off, int nb, int row_bytes, bool snap = false) {
     float fid = __builtin_amdgcn_cubeid(L.x, L.y, L.z);
     float sc = __builtin_amdgcn_cubesc(L.x, L.y, L.z);
     float tc = __builtin_amdgcn_cubetc(L.x, L.y, L.z);
@@ -42,6 +43,7 @@ __device__ __forceinline__ f3 sample_bordered(__amdgpu_buffer_rsrc_t rs, f3 L, f
     float h = __builtin_amdgcn_rcpf(fabsf(ma2)) * nf;            // n / (2 |rc|)
     float u = fmaf(sc, h, off);                                  // s*n - 0.5 + 1 (bordered), in [0.5, n + 0.5]
     float v = fmaf(tc, h, off);
+    if (snap) { u = snap256(u); v = snap256(v); }                // bordered = unbordered + 1: the snap commutes with the offset
     float a = __builtin_amdgcn_fractf(u), b = __builtin_amdgcn_fractf(v);
     if (CELLS) {
         // Cell byte offset in fp32: cells exist for n <= 512 only, so face*nc + j0, the cell index (< 6*513^2 < 2^24) and

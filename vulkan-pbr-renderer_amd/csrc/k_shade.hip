@@ -73,28 +73,29 @@ __device__ __forceinline__ void fill_level_table(int* tab, int W, int levels, in
     __syncthreads();
 }
 __device__ __forceinline__ f3 level_fetch(const float4* __restrict__ pyr, const float4* __restrict__ cells, int cells_first,
-                                          int W, int l, int face, float s, float t, const int* tab) {
+                                          int W, int l, int face, float s, float t, const int* tab, bool snap = false) {
     int n = max(W >> l, 1);
-    CubeTap tp = cube_tap_from_st(face, s, t, n);
+    CubeTap tp = cube_tap_from_st(face, s, t, n, snap);
     if (cells && l >= cells_first) return fetch_rgb_cells_tap(cells + tab[16 + l], n, tp);
     return fetch_rgb_tap(pyr + tab[l], n, tp);
 }
 // trilinear fetch from a bordered pyramid (sampler: linear mip filter, LOD clamped to the chain)
 template <bool kExactDiv>
 __device__ __forceinline__ f3 pyramid_fetch(const float4* __restrict__ pyr, const float4* __restrict__ cells, int cells_first,
-                                            int W, int levels, f3 d, float lod, const int* tab) {
+                                            int W, int levels, f3 d, float lod, const int* tab, bool snap = false) {
     CubeST cs = cube_select(d);
     float s, t;
     if (kExactDiv) cube_st_exact(cs, &s, &t); else cube_st_shared(cs, &s, &t);
     float maxl = (float)(levels - 1);
     lod = fminf(fmaxf(lod, 0.0f), maxl);
+    if (snap) lod = snap256(lod);                                  // diagnostic sampler convention: 8 bits of LOD fraction
     float fl = floorf(lod);
     int l0 = (int)fl;
     float w = lod - fl;
-    f3 c0 = level_fetch(pyr, cells, cells_first, W, l0, cs.face, s, t, tab);
+    f3 c0 = level_fetch(pyr, cells, cells_first, W, l0, cs.face, s, t, tab, snap);
     if (w > 0.0f) {
         int l1 = min(l0 + 1, levels - 1);
-        f3 c1 = level_fetch(pyr, cells, cells_first, W, l1, cs.face, s, t, tab);
+        f3 c1 = level_fetch(pyr, cells, cells_first, W, l1, cs.face, s, t, tab, snap);
         c0.x = lerp_fma(c0.x, c1.x, w); c0.y = lerp_fma(c0.y, c1.y, w); c0.z = lerp_fma(c0.z, c1.z, w);
     }
     return c0;
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
 
         // :708-710 the sky branch replaces everything else: take it first (most waves of a frame are all-sky or all-surface)
         if (sky) {
-            outl = pyramid_fetch<kGI>(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, mk3(-V.x, -V.y, -V.z), 1.0f, level_tab);
+            outl = pyramid_fetch<kGI>(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, mk3(-V.x, -V.y, -V.z), 1.0f, level_tab, p.snap != 0);
         } else {
             if (p.flags & PBRK_SHADE_SHAFTS) {                                   // :622-651
                 float cp4[4];
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
                     CubeST cs = cube_select(N);
                     float si, ti;
                     if (kGI) cube_st_exact(cs, &si, &ti); else cube_st_shared(cs, &si, &ti);
-                    CubeTap tp = cube_tap_from_st(cs.face, si, ti, p.irr_size);
+                    CubeTap tp = cube_tap_from_st(cs.face, si, ti, p.irr_size, p.snap != 0);
                     ambient = p.irr_cells ? fetch_rgb_cells_tap(p.irr_cells, p.irr_size, tp) : fetch_rgb_tap(p.irr, p.irr_size, tp);
                 }
                 float p0_view[4] = {0.0f, 0.0f, 0.0f, 1.0f};
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(256) void k_shade(const ShadeParams p) {
                 float r4 = r2 * r2;
                 R = mk3(mix_(R.x, N.x, r4), mix_(R.y, N.y, r4), mix_(R.z, N.z, r4));
                 f3 spec = mk3(0.0f, 0.0f, 0.0f);
-                if (p.flags & PBRK_SHADE_IBL) spec = pyramid_fetch<kGI>(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, R, roughness * 4.0f, level_tab);   // :699
+                if (p.flags & PBRK_SHADE_IBL) spec = pyramid_fetch<kGI>(p.pre, p.pre_cells, p.pre_cells_first, p.pre_size, p.pre_levels, R, roughness * 4.0f, level_tab, p.snap != 0);   // :699
                 if (gi) spec = sample_radiance_ss(p, V, p0_view, P, R, 16, 2.0f, noise_3, roughness, 0.9f);   // :701
                 outl.x += spec.x * (F0.x * sb.x + sb.y);                                   // :702
                 outl.y += spec.y * (F0.y * sb.x + sb.y);
@@ -634,7 +635,8 @@ extern "C" int pbrk_shade(const PbrkShadeArgs* a, void* stream) {
     // fast instantiation: no sun shadows / GI, power-of-two prefiltered cube with a complete cells twin (and, IBL, the two other twins)
     static int fast_mode = -1;
     if (fast_mode < 0) { const char* e = getenv("PBR_SHADE_FAST"); fast_mode = e ? atoi(e) : 1; }
-    bool fast = fast_mode && !(a->flags & (PBRK_SHADE_GI | PBRK_SHADE_SHADOWS)) && p.pre_cells && p.pre_cells_first == 0 &&
+    p.snap = pbrk_get_cube_sampler_snap();                          // diagnostic cube-sampler convention: general kernel only
+    bool fast = fast_mode && !p.snap && !(a->flags & (PBRK_SHADE_GI | PBRK_SHADE_SHADOWS)) && p.pre_cells && p.pre_cells_first == 0 &&
                 (a->prefiltered_size & (a->prefiltered_size - 1)) == 0 && a->prefiltered_size <= 512 &&
                 (long long)a->width * a->height < (1ll << 29);
     if (fast && (a->flags & PBRK_SHADE_IBL)) fast = p.irr_cells && p.lut_cells && a->irradiance_size <= 512;

@@ -21,6 +21,7 @@ struct ShadeParams {
     // tiled instantiation (k_shade_tile.hip): per-column / per-row tables of the frame and wave-uniform constants, all computed on the host
     const float4* col_tab; const float4* row_tab;
     float irr_nf, irr_off1, noise_offset, pre_maxl, pre_wf, lut_sf;
+    int snap;                      // cube-sampler convention (pbrk_set_cube_sampler_snap): general kernel only
     int dbg; void* dbg_stats;      // -DPBR_K5_DEBUG builds only (tools/k5_tile_probe.sh): 1 = no staging, 2 = every lane reads LDS, 4 = window hit counters
     const float* sun_depth; int sun_w, sun_h;
     // voxel GI (PBRK_SHADE_GI)

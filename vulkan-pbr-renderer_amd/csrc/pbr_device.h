@@ -132,9 +132,13 @@ __device__ __forceinline__ void cube_st_shared(const CubeST& c, float* s, float*
     *s = div_by(0.5f * c.sc, rma) + 0.5f;
     *t = div_by(0.5f * c.tc, rma) + 0.5f;
 }
-__device__ __forceinline__ CubeTap cube_tap_from_st(int face, float s, float t, int n) {
+// Sampler-coordinate convention: exact fp32 (default) or -- pbrk_set_cube_sampler_snap(1), general kernels only --
+// snapped to 1/256 texel, the sub-texel resolution of real texture units (and of this repo's 2-D / 3-D samplers).
+__device__ __forceinline__ float snap256(float x) { return floorf(x * 256.0f + 0.5f) * (1.0f / 256.0f); }
+__device__ __forceinline__ CubeTap cube_tap_from_st(int face, float s, float t, int n, bool snap = false) {
     float u = s * (float)n - 0.5f;                        // unbordered coordinate, as the sampler definition states it
     float v = t * (float)n - 0.5f;
+    if (snap) { u = snap256(u); v = snap256(v); }
     float fu = floorf(u), fv = floorf(v);
     int i0 = min(max((int)fu + 1, 0), n), j0 = min(max((int)fv + 1, 0), n);   // +1: bordered layout
     CubeTap tp;
@@ -151,12 +155,12 @@ __device__ __forceinline__ CubeTap cube_tap_from_st(int face, float s, float t, 
 //                (single-sample lookups: K4a copy, shade pass) so that tap selection and weights are
 //                bit-identical to a scalar CPU evaluation even next to a 5e4:1 HDR sun texel.
 template <bool EXACT>
-__device__ __forceinline__ CubeTap cube_tap(f3 d, int n) {
+__device__ __forceinline__ CubeTap cube_tap(f3 d, int n, bool snap = false) {
     CubeST c = cube_select(d);
     if (EXACT) {
         float s, t;
         cube_st_exact(c, &s, &t);
-        return cube_tap_from_st(c.face, s, t, n);
+        return cube_tap_from_st(c.face, s, t, n, snap);
     }
     float h = 0.5f * __builtin_amdgcn_rcpf(c.ma) * (float)n;     // (0.5 / |rc|) * n
     float off = 0.5f * (float)n + 0.5f;                          // s*n - 0.5 + 1 = sc*h + n/2 + 0.5 (bordered)
@@ -221,8 +225,8 @@ __device__ __forceinline__ f3 cube_fetch_rgb(const float4* __restrict__ lvl, int
 }
 
 template <bool EXACT>
-__device__ __forceinline__ float4 cube_fetch_rgba(const float4* __restrict__ lvl, int n, f3 d) {
-    CubeTap t = cube_tap<EXACT>(d, n);
+__device__ __forceinline__ float4 cube_fetch_rgba(const float4* __restrict__ lvl, int n, f3 d, bool snap = false) {
+    CubeTap t = cube_tap<EXACT>(d, n, snap);
     int nb = n + 2;
     float4 t00 = lvl[t.base], t10 = lvl[t.base + 1];
     float4 t01 = lvl[t.base + nb], t11 = lvl[t.base + nb + 1];
