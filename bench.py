@@ -62,6 +62,55 @@ def load_env(W, seed, workers):
     return a
 
 
+def sha256_of(paths):
+    import hashlib
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 20), b""):
+                h.update(chunk)
+    return h.hexdigest()
+
+
+def inspect_hdr(path):
+    """Resolution line of a Radiance file -> layout (the decode itself is the C host layer's: PBR_DecodeHDR)."""
+    with open(path, "rb") as f:
+        head = f.read(4096)
+    if not head.startswith(b"#?"):
+        raise SystemExit(f"{path}: not a Radiance .hdr file")
+    import re as _re
+    m = _re.search(rb"\n\n-Y (\d+) \+X (\d+)\n", head)
+    if not m:
+        raise SystemExit(f"{path}: only the standard -Y H +X W orientation is supported (as stb_image.h:7196)")
+    h, w = int(m.group(1)), int(m.group(2))
+    if h == 6 * w:
+        layout = "cube strip"
+    elif w == 2 * h:
+        layout = "equirectangular"
+    else:
+        raise SystemExit(f"{path}: {w}x{h} is neither a 6-face strip (height == 6 x width) nor a 2:1 panorama")
+    return {"path": os.path.abspath(path), "width": w, "height": h, "layout": layout, "sha256": sha256_of([path])}
+
+
+def load_gbuffer_dir(d):
+    names = ("base_color", "normal", "orm", "emissive", "depth")
+    paths = [os.path.join(d, n + ".npy") for n in names]
+    arrs = [np.load(p, allow_pickle=False) for p in paths]
+    H, W = arrs[4].shape
+    for a in arrs[:4]:
+        if a.dtype != np.uint8 or a.shape != (H, W, 4):
+            raise SystemExit(f"{d}: colour planes must be uint8 [H][W][4] matching depth.npy ({W}x{H})")
+    if arrs[4].dtype != np.float32:
+        raise SystemExit(f"{d}: depth.npy must be float32 [H][W]")
+    cam = {"pos": [0.0, -9.0, 0.0], "ori_xyzw": None, "fov": 75.0}
+    cj = os.path.join(d, "camera.json")
+    if os.path.exists(cj):
+        cam.update(json.load(open(cj)))
+        paths.append(cj)
+    return {"base": arrs[0], "normal": arrs[1], "orm": arrs[2], "emissive": arrs[3], "depth": arrs[4], "camera": cam,
+            "info": {"dir": os.path.abspath(d), "width": int(W), "height": int(H), "sha256": sha256_of(paths)}}
+
+
 def nonzero_weight_count(L, nsamples, roughness):
     tab = np.zeros((nsamples, 4), np.float32)
     alpha = C.c_float()
@@ -148,6 +197,14 @@ def main():
                     help="record the job as two graphs (mip-1 units first) and send each part while the next computes (PBR_RunPartitionedIBL; "
                          "needs the C gather for N > 1; opt-in: never run on more than one GPU)")
     ap.add_argument("--check", action="store_true", help="after the run, spot-check output texels against the oracle")
+    ap.add_argument("--hdr", default=None, metavar="FILE.hdr",
+                    help="real environment instead of the synthetic one: a Radiance .hdr cube strip (height == 6 x width, the reference's "
+                         "layout, asset_import.cpp:17-27 -> PBR_MakeTextureFromHDRIFile) or an equirectangular panorama (width == 2 x "
+                         "height -> PBR_MakeTextureFromEquirectHDRIFile at the workload's cube size); `data` becomes \"file\" with its SHA-256")
+    ap.add_argument("--gbuffer", default=None, metavar="DIR",
+                    help="real G-buffer for the 1920x1080-class shade leg (extra.shade): DIR holds base_color.npy, normal.npy, orm.npy, "
+                         "emissive.npy (uint8 [H][W][4], the RGBA8 attachments of render.cpp:680-687), depth.npy (float32 [H][W]) and "
+                         "optionally camera.json {\"pos\": [x,y,z], \"ori_xyzw\": [..], \"fov\": deg}")
     ap.add_argument("--dry-launch", action="store_true", help="print the worker command `--gpus N` would start and exit 0 (no GPU, no torch)")
     args = ap.parse_args()
 
@@ -179,7 +236,13 @@ def main():
 
     W, spec_size, irr_size, seed, desc = WORKLOADS[args.workload]
     # inputs first (fork-based workers), GPU afterwards
-    env = load_env(W, seed, workers=max(1, min(6, (os.cpu_count() or 8) // max(1, world))))
+    hdr_info = None
+    if args.hdr:
+        hdr_info = inspect_hdr(args.hdr)                                          # dims + layout + SHA-256; the file itself is decoded by the C host layer
+        env = None
+    else:
+        env = load_env(W, seed, workers=max(1, min(6, (os.cpu_count() or 8) // max(1, world))))
+    gb_file = load_gbuffer_dir(args.gbuffer) if args.gbuffer else None
     c5_gbd = None
     if not args.no_shade and not args.no_c5:                      # this rank's band of the 7680x4320 G-buffer (worker processes: before the GPU is touched)
         from pbrhip import synth
@@ -239,7 +302,18 @@ def main():
             rccl_report["error"] = repr(e)
 
     # ---- resources: env cube (level 0 resident), output maps over torch-owned HBM (so RCCL can move them)
-    env_tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, W, W, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+    if hdr_info is not None:
+        if hdr_info["layout"] == "cube strip":
+            env_tex = L.PBR_MakeTextureFromHDRIFile(args.hdr.encode())            # asset_import.cpp:17-27: decode, upload, mip chain
+        else:
+            env_tex = L.PBR_MakeTextureFromEquirectHDRIFile(args.hdr.encode(), W)  # N1: panorama -> W^2 cube (K6) + mip chain
+        if not env_tex:
+            raise RuntimeError(f"{args.hdr}: the host layer could not load it")
+        W = int(env_tex.contents.width)
+        env = pbrhip.read_mip(env_tex, 0)                                          # what the oracle legs (cpu_baseline, --check) are fed
+        desc += f" [environment from file: {hdr_info['layout']}, cube {W}^2]"
+    else:
+        env_tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, W, W, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
     spec_flags = pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps | pbrhip.TextureFlag_StorageImage
     n_mips = L.pbrk_mip_count(spec_size, spec_size)
     spec_floats = L.pbrk_pyramid_texels(spec_size, n_mips) * 4
@@ -463,7 +537,7 @@ def main():
     extra = {}
     if rank == 0 and not args.no_shade:
         try:
-            extra["shade"] = shade_bench(L, pbrhip, env_tex, world)
+            extra["shade"] = shade_bench(L, pbrhip, env_tex, world, gb_file=gb_file)
         except Exception as e:      # the headline number must not depend on the extra
             extra["shade_error"] = repr(e)
         try:
@@ -534,8 +608,10 @@ def main():
             "metric": "IBL-prefilter Mtexels/s (specular prefilter all mips + irradiance; PBR-shaded Mpixels/s under extra.shade_c5 / extra.shade)",
             "value": value, "unit": "Mtexels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "env": f"procedural HDR cube {W}^2 x6 RGBA32F (seed {seed:#x}, RGBE round-tripped)",
+            "dtype": "f32", "data": "file" if (hdr_info or gb_file) else "synthetic",
+            "inputs": ({"hdr": hdr_info} if hdr_info else {}) | ({"gbuffer": gb_file["info"]} if gb_file else {}) or None,
+            "config": {"workload": desc, "env": (f"{os.path.basename(args.hdr)} sha256 {hdr_info['sha256']}" if hdr_info else
+                                                 f"procedural HDR cube {W}^2 x6 RGBA32F (seed {seed:#x}, RGBE round-tripped)"),
                        "texels_per_step": total_texels, "sample_evaluations_per_step": sample_evals,
                        "overlap": overlap, "parallelism": "single GPU" if world == 1 else f"{world} ranks, weighted linear partition of output rows (3-8 dispatches per rank), 1 grouped RCCL send/recv gather per step"},
             "roofline": roofline, "roofline_hbm": roofline_hbm, "rates": rates, "step_split": step_split, "rccl": rccl_report, "kernels": kernels[:12],
@@ -553,12 +629,18 @@ def main():
         dist.destroy_process_group()
 
 
-def shade_bench(L, pbrhip, env_tex, world, frames=20):
+def shade_bench(L, pbrhip, env_tex, world, frames=20, gb_file=None):
     """C3: 1920x1080 synthetic metal-rough-spheres G-buffer through the lighting pass (K5); IBL maps at the reference's sizes
     (render.cpp:794-796: 32^2 irradiance, 256^2 LUT, 256^2 prefiltered cube with mips down to 16^2) from this run's environment."""
     from pbrhip import synth
-    W, H = 1920, 1080
-    gbd = synth.synth_gbuffer_spheres(W, H)
+    if gb_file is not None:                                                # --gbuffer DIR: the planes as the raster passes would have left them
+        gbd = gb_file
+        H, W = gbd["depth"].shape
+        cam = gbd["camera"]
+    else:
+        W, H = 1920, 1080
+        gbd = synth.synth_gbuffer_spheres(W, H)
+        cam = {"pos": gbd["cam_pos"], "ori_xyzw": None, "fov": 75.0}
     maps = pbrhip.PBR_IBLMaps()
     L.PBR_MakeIBLMaps(C.byref(maps), 32, 256, 256)
     L.PBR_GenIrradianceMap(env_tex, maps.irradiance_map)
@@ -570,7 +652,7 @@ def shade_bench(L, pbrhip, env_tex, world, frames=20):
                       ("emissive", gbd["emissive"]), ("depth", gbd["depth"])):
         pbrhip.upload_mip(getattr(gb, name), 0, arr)
     lp = L.PBR_MakeLightingPass(C.byref(gb), C.byref(maps), W, H)
-    glob = pbrhip.fill_globals(gbd["cam_pos"], aspect=W / H)
+    glob = pbrhip.fill_globals(cam["pos"], ori=cam.get("ori_xyzw"), fov=float(cam.get("fov", 75.0)), aspect=W / H)
     g = L.GPU_MakeGraph()
     L.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
     L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)                      # warm-up (builds the aprons)
@@ -583,7 +665,8 @@ def shade_bench(L, pbrhip, env_tex, world, frames=20):
           if L.GPUX_GraphTimedOpName(g, i).decode() == "K5.shade"]
     k_ms = float(np.mean(ms)) if ms else float("nan")
     byt = 28.0 * W * H
-    res = {"workload": "C3: 1920x1080 G-buffer Cook-Torrance shade pass (IBL mode), RGBA16F target", "frames": frames,
+    res = {"workload": (f"G-buffer from {gb_file['info']['dir']} ({W}x{H}), Cook-Torrance shade pass (IBL mode), RGBA16F target" if gb_file is not None
+                        else "C3: 1920x1080 G-buffer Cook-Torrance shade pass (IBL mode), RGBA16F target"), "frames": frames,
            "kernel_avg_ms": k_ms, "mpixels_per_s_kernel": W * H / (k_ms * 1e-3) / 1e6,
            "mpixels_per_s_wall": W * H * frames / wall / 1e6,
            "roofline": {"kernel": "K5.shade", "bound": "hbm", "achieved": byt / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
