@@ -147,6 +147,40 @@ def _run_prefilter(gpu, env_tex, out_size, min_size):
     return spec
 
 
+@pytest.mark.parametrize("nsamples", [5000, 12288])
+def test_brdf_lut_any_sample_count(gpu, nsamples):
+    """K1 keeps the sample directions in LDS; since round 3 they pass through it in chunks of 4096, so sample counts
+    beyond one chunk (a ragged second chunk: 5000; three chunks: 12288 -- more than the 9600 that once fitted) work and equal the
+    oracle.  Low-level kernel ABI (pbrk_brdf_lut) with the host tables, 64^2 map, fp32 target."""
+    import pbrhip, pbr_oracle as O
+    L = gpu
+    size = 64
+    ang = np.zeros((nsamples, 4), np.float32)
+    L.pbrk_host_sample_angles(nsamples, ang.ctypes.data_as(C.c_void_p))
+    libm = C.CDLL("libm.so.6")                                                      # the host's fp32 libm, as the backend builds its table (gpu_hip.cpp)
+    for fn in (libm.acosf, libm.cosf, libm.sinf):
+        fn.restype = C.c_float; fn.argtypes = [C.c_float]
+    vcs = np.zeros((size, 2), np.float32)
+    for x in range(size):                                                           # V = Rotate((0,0,1), (1,0,0), acos(NdotV)): cos / sin of that angle
+        th = libm.acosf(C.c_float(float((np.float32(x) + np.float32(0.5)) / np.float32(size))))
+        vcs[x] = (libm.cosf(th), libm.sinf(th))
+    d_ang = L.GPU_MakeBuffer(ang.nbytes, pbrhip.BufferFlag_GPU, ang.ctypes.data_as(C.c_void_p))
+    d_vcs = L.GPU_MakeBuffer(vcs.nbytes, pbrhip.BufferFlag_GPU, vcs.ctypes.data_as(C.c_void_p))
+    out = L.GPU_MakeBuffer(size * size * 8, pbrhip.BufferFlag_GPU, None)
+    host = L.GPU_MakeBuffer(size * size * 8, pbrhip.BufferFlag_CPU, None)
+    assert L.pbrk_brdf_lut(L.GPUX_BufferDevicePtr(out), pbrhip.PBRK_FMT_RG32F, size, nsamples, L.GPUX_BufferDevicePtr(d_ang), L.GPUX_BufferDevicePtr(d_vcs), 0, size, None) == 0
+    g = L.GPU_MakeGraph()
+    L.GPU_WaitUntilIdle()
+    L.GPU_OpCopyBufferToBuffer(g, out, host, 0, 0, size * size * 8); L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    got = np.frombuffer((C.c_char * (size * size * 8)).from_address(host.contents.data), np.float32).reshape(size, size, 2).copy()
+    want = O.brdf_lut(size, nsamples)[..., :2]
+    e = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-3)
+    assert e.max() < REL, float(e.max())
+    L.GPU_DestroyGraph(g)
+    for b in (d_ang, d_vcs, out, host):
+        L.GPU_DestroyBuffer(b)
+
+
 def test_prefilter_env64_vs_oracle_a(gpu, env64, golden_dir):
     """K4a/K4b on the textured W=64 environment vs Oracle-A fixtures (mips 0-2 of a 64^2 cube)."""
     import pbrhip
