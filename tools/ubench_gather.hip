@@ -90,6 +90,15 @@ __global__ __launch_bounds__(256) void k_loads(const void* cells, int bytes, flo
             acc += (a.x ^ a.w) + (a.y ^ a.z);
         } else if (MODE == 5) {
             acc += __builtin_amdgcn_raw_buffer_load_b32(r, cell * 64 + rot, 0, 0);
+        } else if (MODE == 8) {                            // coalesced: 64 lanes x 4 B = 256 contiguous bytes (a G-buffer plane of 64 pixels)
+            acc += __builtin_amdgcn_raw_buffer_load_b32(r, ((blockIdx.x * 4 + wv) % 512) * 4096 + lane * 4 + rot, 0, 0);
+        } else if (MODE == 9) {                            // coalesced: 64 lanes x 16 B = 1 KB contiguous (4 pixels of a plane per lane)
+            u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, ((blockIdx.x * 4 + wv) % 512) * 4096 + lane * 16 + rot, 0, 0);
+            acc += (a.x ^ a.w) + (a.y ^ a.z);
+        } else if (MODE == 10) {                           // coalesced: 64 lanes x 8 B
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(r, ((blockIdx.x * 4 + wv) % 512) * 4096 + lane * 8 + rot, 0, 0);
+            acc += a.x ^ a.y;
         } else if (MODE == 7) {                            // three lanes of a quad fetch one 48-byte cell (16-byte aligned), the fourth sits out
             u32x4 v[4];
             const int piece = (lane & 3) == 3 ? 0x7FFFFFF0 : (lane & 3) * 16;
@@ -145,9 +154,10 @@ int main() {
                    ms * 1e-3 * 2.4e9 * 256 / wave_iters);
         }
     }
-    const char* ln[8] = {"3 scattered x4 (48 B cells)", "3 scattered x4 (64 B cells)", "4 quad-coop x4 + LDS", "3 coherent x4", "1 scattered x4", "1 scattered dword", "4 quad-coop x4, no LDS", "4 tri-coop x4 (48 B cells) + LDS"};
+    const char* ln[11] = {"3 scattered x4 (48 B cells)", "3 scattered x4 (64 B cells)", "4 quad-coop x4 + LDS", "3 coherent x4", "1 scattered x4", "1 scattered dword", "4 quad-coop x4, no LDS", "4 tri-coop x4 (48 B cells) + LDS",
+                          "1 coalesced dword (256 B / wave)", "1 coalesced dwordx4 (1 KB / wave)", "1 coalesced dwordx2 (512 B / wave)"};
     for (int window : {21, 9}) {
-        for (int mode = 0; mode < 8; ++mode) {
+        for (int mode = 0; mode < 11; ++mode) {
             float ms = 0; const int iters = 256, lb = 256 * 8 * 2;
             for (int rep = 0; rep < 3; ++rep) {
                 hipEventRecord(e0);
@@ -159,6 +169,9 @@ int main() {
                 case 4: hipLaunchKernelGGL(k_loads<4>, dim3(lb), dim3(256), 0, 0, d, bytes, o, window, iters); break;
                 case 5: hipLaunchKernelGGL(k_loads<5>, dim3(lb), dim3(256), 0, 0, d, bytes, o, window, iters); break;
                 case 7: hipLaunchKernelGGL(k_loads<7>, dim3(lb), dim3(256), 0, 0, d, bytes, o, window, iters); break;
+                case 8: hipLaunchKernelGGL(k_loads<8>, dim3(lb), dim3(256), 0, 0, d, bytes, o, window, iters); break;
+                case 9: hipLaunchKernelGGL(k_loads<9>, dim3(lb), dim3(256), 0, 0, d, bytes, o, window, iters); break;
+                case 10: hipLaunchKernelGGL(k_loads<10>, dim3(lb), dim3(256), 0, 0, d, bytes, o, window, iters); break;
                 default: hipLaunchKernelGGL(k_loads<6>, dim3(lb), dim3(256), 0, 0, d, bytes, o, window, iters); break;
                 }
                 hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);

@@ -1472,8 +1472,12 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
     case Op_Clear: {
         TextureImpl* t = op.tex;
         uint32_t m0 = op.mip == GPU_MIP_LEVEL_ALL ? 0 : op.mip, m1 = op.mip == GPU_MIP_LEVEL_ALL ? t->base.mip_level_count : op.mip + 1;
-        for (uint32_t m = m0; m < m1; ++m) {
-            size_t bytes = (size_t)GPUX_TextureMipBytes(&t->base, m);
+        // Levels are back to back in the allocation ([mip][layer][y][x], tight), so GPU_MIP_LEVEL_ALL is ONE fill of the whole
+        // texture instead of one per level: the reference clears bloom_upscale_rt this way every frame (render.cpp:1156; 11 levels at
+        // 1080p = 11 fill kernels of ~5 us each in rocprofv3's trace, a quarter of the post-process tail, before round 3).
+        const bool whole = op.mip == GPU_MIP_LEVEL_ALL;
+        for (uint32_t m = m0; m < (whole ? m0 + 1 : m1); ++m) {
+            size_t bytes = whole ? t->bytes : (size_t)GPUX_TextureMipBytes(&t->base, m);
             void* p = (char*)t->dev + t->mip_offset[m];
             // build one texel pattern on the host and replicate it (clears are rare: upload a staging row)
             uint32_t tb = t->texel_bytes;
