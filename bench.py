@@ -486,12 +486,16 @@ def main():
 
     # HBM traffic per launch from the committed rocprofv3 PMC summary of this same command (profiles/, separate
     # --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction, WRITE_SIZE exact)
-    pmc, pmc_file = {}, f"profiles/r02_{args.workload}_pmc.json"
-    try:
-        with open(os.path.join(ROOT, pmc_file)) as f:
-            pmc = json.load(f).get("kernels", {})
-    except Exception:
-        pass
+    pmc, pmc_file = {}, None
+    for rnd in ("r03", "r02"):                                  # the newest committed summary of this workload
+        cand = f"profiles/{rnd}_{args.workload}_pmc.json"
+        try:
+            with open(os.path.join(ROOT, cand)) as f:
+                pmc = json.load(f).get("kernels", {})
+            pmc_file = cand
+            break
+        except Exception:
+            continue
     traffic_keys = {}                                   # which entry of the profile file each traffic figure came from (staleness is visible)
 
     def traffic_for(kernel_prefix, grid_threads, who=None):

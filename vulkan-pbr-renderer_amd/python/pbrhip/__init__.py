@@ -233,6 +233,7 @@ PROTOTYPES = {
     "pbrk_cells_bytes": (C.c_size_t, [C.c_int]), "pbrk_cells_build": (C.c_int, [VP, C.c_int, VP, VP]),
     "pbrk_shade": (C.c_int, [C.POINTER(PbrkShadeArgs), VP]),
     "pbrk_shade_set_tile_min_pixels": (None, [C.c_longlong]), "pbrk_shade_tables_ready": (C.c_int, [C.c_int, C.c_int]),
+    "pbrk_shade_needs_tables": (C.c_int, [C.c_int, C.c_int]),
     "pbrk_mc_region_stats": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
     "pbrk_mc_region_flag_stats": (C.c_int, [C.POINTER(C.c_uint64)]), "pbrk_mc_region_window_stats": (C.c_int, [C.POINTER(C.c_uint64)]),
     "pbrk_lut_cells_build": (C.c_int, [VP, C.c_int, VP, VP]),
