@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+REL = 1e-4          # north_star: 1e-4 relative per texel
 
 
 def _prefilter(gpu, env, spec_size, min_size=1):
@@ -337,3 +338,59 @@ def test_bench_accepts_real_files_by_path(gpu, tmp_path):
         assert out["inputs"]["gbuffer"]["width"] == 320 and out["extra"]["shade"]["mpixels_per_s_kernel"] > 0, out["extra"].get("shade_error")
         assert "320x180" in out["extra"]["shade"]["workload"]
         assert out["extra"]["check_max_rel_err_vs_oracle"] < 1e-4
+
+
+def test_soak_random_environments_and_rows(gpu):
+    """the soak of tools/soak_ibl.py as a (bounded) test.  Four random HDR environments (seeded: size, output size, sun
+    direction at 5e4:1 contrast) through the whole precompute -- every texel of every mip and the irradiance map vs the oracle at 1e-4,
+    mip chain bit for bit -- then two environments at sizes the region kernel serves (256 -> 512, 512 -> 1024): three random
+    (face, row) pairs of every level >= 256^2 vs the oracle.  The region kernel's completeness counter must stay at zero."""
+    import pbrhip, pbr_oracle as O
+    from pbrhip import synth
+    L = gpu
+    rng = np.random.default_rng(0x50AC)
+    sun0 = synth.SUN_DIR.copy()
+
+    def rel(a, b, floor=1e-3):
+        return float((np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b), floor)).max())
+    try:
+        for run in range(4):
+            W = int(rng.choice([32, 64, 128])); out = int(rng.choice([16, 32, 64]))
+            d = rng.normal(size=3); synth.SUN_DIR = d / np.linalg.norm(d)
+            env = synth.synth_env(W, seed=int(rng.integers(1, 2 ** 31)), workers=1)
+            pyr = O.build_pyramid(env)
+            tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, W, W, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+            maps = pbrhip.PBR_IBLMaps()
+            L.PBR_MakeIBLMaps(C.byref(maps), 16, 64, out)
+            L.PBR_GenPrefilteredEnvMap(tex, maps.tex_specular_env_map, 1)
+            L.PBR_GenIrradianceMap(tex, maps.irradiance_map)
+            for m in range(maps.tex_specular_env_map.contents.mip_level_count):
+                e = rel(pbrhip.read_mip(maps.tex_specular_env_map, m), O.prefilter_mip(pyr, W, out, m))
+                assert e < REL, (run, W, out, m, e)
+            assert rel(pbrhip.read_mip(maps.irradiance_map, 0)[..., :3], O.irradiance(pyr, W, 16)[..., :3]) < REL, (run, W)
+            for l in range(tex.contents.mip_level_count):
+                assert np.array_equal(pbrhip.read_mip(tex, l), O.pyramid_level(pyr, W, l)), (run, l)
+            L.PBR_DestroyIBLMaps(C.byref(maps)); L.GPU_DestroyTexture(tex)
+        for (W, out) in ((256, 512), (512, 1024)):
+            d = rng.normal(size=3); synth.SUN_DIR = d / np.linalg.norm(d)
+            env = synth.synth_env(W, seed=int(rng.integers(1, 2 ** 31)), workers=1)
+            pyr = O.build_pyramid(env)
+            tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, W, W, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+            maps = pbrhip.PBR_IBLMaps()
+            L.PBR_MakeIBLMaps(C.byref(maps), 16, 64, out)
+            L.PBR_GenPrefilteredEnvMap(tex, maps.tex_specular_env_map, 256)
+            for m in range(maps.tex_specular_env_map.contents.mip_level_count):
+                size = out >> m
+                if size < 256:
+                    break
+                got = pbrhip.read_mip(maps.tex_specular_env_map, m)
+                for _ in range(3):
+                    f, y = int(rng.integers(0, 6)), int(rng.integers(0, size))
+                    want = O.prefilter_mip(pyr, W, out, m, faces=(f, f + 1), rows=(y, y + 1))[f, y]
+                    assert rel(got[f, y], want) < REL, (W, out, m, f, y)
+            L.PBR_DestroyIBLMaps(C.byref(maps)); L.GPU_DestroyTexture(tex)
+    finally:
+        synth.SUN_DIR = sun0
+    st = (C.c_uint64 * 2)()
+    if L.pbrk_mc_region_stats(st, 0) == 0:
+        assert st[0] == 0, f"{st[0]} of {st[1]} wave-slices had to be recomputed"
