@@ -73,6 +73,16 @@ GPU_API void GPUX_EnableOpTiming(int enable);
 GPU_API uint32_t GPUX_GraphTimedOpCount(GPU_Graph* graph);          /* ops of the last waited submission */
 GPU_API const char* GPUX_GraphTimedOpName(GPU_Graph* graph, uint32_t index);
 GPU_API float GPUX_GraphTimedOpMs(GPU_Graph* graph, uint32_t index);
+/* ---- tolerance-budgeted sample cut of the specular prefilter (opt-in, NEVER the default: the reference sums every sample) ----
+ * The Monte-Carlo weights of a low-roughness level decay like exp(-i / 14.7): of mip 1's 1389 non-zero fp32 weights the last ~900
+ * together carry less than 1e-13 of the sum.  With rel > 0 a prefilter dispatch keeps the first K samples, K the smallest count with
+ *     (sum of dropped weights) * max(source level)  <=  rel * (sum of kept weights) * min(source level)
+ * -- a rigorous bound on every texel's relative error (taps are convex combinations of the level's texels), evaluated on the host
+ * from the weight table and the level's measured range (one reduction + read-back per source level and content change).  A level
+ * with a zero or negative texel is never cut.  rel = 0 (default) restores the exact sum.  GPUX_PrefilterKeptSamples(mip): what the
+ * last dispatch of that output mip kept (0: none recorded). */
+GPU_API void GPUX_SetPrefilterTolerance(float rel);
+GPU_API int GPUX_PrefilterKeptSamples(uint32_t mip_level);
 /* busy span of the last waited submission on the graph's main stream: one event pair from before its first op to after the
  * last join of its side streams (overlapping dispatches are not counted twice, unlike the sum of the per-op times) */
 GPU_API float GPUX_GraphSpanMs(GPU_Graph* graph);

@@ -73,6 +73,9 @@ int pbrk_mip_chain(void* pyramid, int W, int levels, void* stream);
  * tap weights.  1: texel coordinates and the LOD fraction snapped to 1/256, the sub-texel / mip-fraction resolution of real
  * texture units and of this repo's 2-D / 3-D samplers.  With 1, K3 / K4a / K4b / K5 run their general kernels (the fast ones
  * implement the default only): a switch to measure how far the outputs move between the two, not a production mode. */
+/* {min, max} over the RGB values of `texels` float4 texels as fp32 bit patterns in out2_device (two unsigned, initialised by the
+ * caller to {0x7F800000, 0}); a negative or NaN input reports min = 0.  Used by the tolerance-budgeted sample cut. */
+int pbrk_level_minmax(const void* level, size_t texels, void* out2_device, void* stream);
 void pbrk_set_cube_sampler_snap(int on);
 int pbrk_get_cube_sampler_snap(void);
 /* one exact 2:1 linear blit (GPU_OpBlit, gpu_vulkan.c:2786-2826) of `nlayers` square RGBA32F layers of size ns */

@@ -529,6 +529,46 @@ def test_cube_sampler_convention_switch(gpu, env64):
     assert d_copy < REL and d_mc > REL and d_frame > REL, (d_copy, d_mc, d_frame)
 
 
+def test_prefilter_tolerance_budgeted_sample_cut(gpu, env64):
+    """GPUX_SetPrefilterTolerance (opt-in): a prefilter dispatch keeps the shortest prefix of its weight table whose
+    dropped tail is rigorously bounded -- tail * max(level) <= rel * head * min(level) -- so every texel moves by at most `rel`
+    relative.  On the textured 64^2 environment with rel = 1e-7: mip 1 (roughness 0.03) keeps a fraction of its 1389 samples, the result
+    stays within 1e-6 of the exact GPU sum (rel + fp32 rounding of a shorter sum) and within 1e-4 of the oracle; rougher mips keep
+    (almost) everything; an environment with one black texel is never cut; rel = 0 restores the exact sums bit for bit."""
+    import pbrhip, pbr_oracle as O
+    L = gpu
+    env, tex = env64
+    pyr = O.build_pyramid(env)
+    exact = _run_prefilter(L, tex, 64, 8)
+    ref = [pbrhip.read_mip(exact, m).copy() for m in range(4)]
+    full = [L.GPUX_PrefilterKeptSamples(m) for m in range(4)]
+    assert full[1] == 1389 and full[2] == 8192
+    try:
+        L.GPUX_SetPrefilterTolerance(1e-7)
+        cut = _run_prefilter(L, tex, 64, 8)
+        kept = [L.GPUX_PrefilterKeptSamples(m) for m in range(4)]
+        assert 100 < kept[1] < 900, kept                                  # exp(-i / 14.7) decay: a few hundred samples carry all but 1e-7 / range
+        assert kept[2] <= full[2] and kept[3] <= full[3]
+        for m in range(1, 4):
+            got = pbrhip.read_mip(cut, m)
+            assert rel_err(got[..., :3], ref[m][..., :3], floor=1e-3) < 1e-6, (m, rel_err(got[..., :3], ref[m][..., :3], floor=1e-3))
+            assert np.array_equal(got[..., 3], ref[m][..., 3])             # alpha = the full weight sum, evaluated on the host: untouched
+            assert rel_err(got, O.prefilter_mip(pyr, 64, 64, m), floor=1e-3) < REL
+        L.GPU_DestroyTexture(cut)
+        # a black texel anywhere in the sampled level: the bound is void, nothing is cut
+        env0 = env.copy(); env0[2, :16, :16, :3] = 0.0
+        tex0 = pbrhip.make_texture(pbrhip.Format_RGBA32F, 64, 64, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env0)
+        s0 = _run_prefilter(L, tex0, 64, 8)
+        assert L.GPUX_PrefilterKeptSamples(1) == 1389
+        L.GPU_DestroyTexture(s0); L.GPU_DestroyTexture(tex0)
+    finally:
+        L.GPUX_SetPrefilterTolerance(0.0)
+    again = _run_prefilter(L, tex, 64, 8)
+    for m in range(4):
+        assert np.array_equal(pbrhip.read_mip(again, m).view(np.uint32), ref[m].view(np.uint32))
+    L.GPU_DestroyTexture(again); L.GPU_DestroyTexture(exact)
+
+
 @pytest.mark.parametrize("mode", ["live_shafts_shadows", "ibl_shadows"])
 def test_shade_sun_shadows_vs_oracle(gpu, mode):
     """lighting_pass.glsl:594-608 (4-tap PCF sun shadow) and :646 (light-shaft visibility) with a synthetic sun depth map bound to

@@ -69,6 +69,8 @@ struct TextureImpl {
     // 2x2-footprint "cells" twin of the levels with n <= 512 (levels cells_first.., back to back), built per level on demand
     void* cells = nullptr; int cells_first = 0; std::vector<size_t> cells_off; std::vector<char> cells_valid;
     void* lut_cells = nullptr; bool lut_cells_valid = false;      // RG16F 2-D textures sampled by the shade pass
+    // {min, max} of a level's RGB values (GPUX_SetPrefilterTolerance), measured on demand; dropped with the cells twin
+    std::vector<char> range_valid; std::vector<float> range_min, range_max; void* range_dev = nullptr;
 };
 struct BufferImpl {
     GPU_Buffer base;
@@ -138,7 +140,7 @@ struct GPU_Graph {
     float span_ms = 0.0f;
 };
 
-struct DeviceTable { void* dev = nullptr; int count = 0; float alpha = 0.0f; };
+struct DeviceTable { void* dev = nullptr; int count = 0; float alpha = 0.0f; std::vector<float> weights; /* prefilter tables: w_i of the kept entries, in order */ };
 struct TableKey {
     int kind, n, aux; uint32_t rbits;
     bool operator<(const TableKey& o) const {
@@ -157,6 +159,8 @@ static struct {
     GPU_Sampler samplers[6];
     std::map<TableKey, DeviceTable> tables;
     bool timing = false;
+    float prefilter_tol = 0.0f;                     // GPUX_SetPrefilterTolerance: 0 = exact sums (default)
+    int kept_samples[32] = {0};                     // per output mip: samples kept by the last prefilter dispatch
     int replay = -1;                                // GPUX_SetGraphReplay: submissions go through an instantiated hipGraph (-1: PBR_GRAPH_REPLAY or 0)
 } G;
 
@@ -458,6 +462,7 @@ GPU_API void GPU_DestroyTexture(GPU_Texture* tex) {
     if (t->owns_memory) (void)hipFree(t->dev);
     if (t->bordered) (void)hipFree(t->bordered);
     if (t->cells) (void)hipFree(t->cells);
+    if (t->range_dev) (void)hipFree(t->range_dev);
     if (t->lut_cells) (void)hipFree(t->lut_cells);
     delete t;
 }
@@ -674,6 +679,8 @@ static DeviceTable* get_table(int kind, int n, float roughness, int aux) {
     if (kind == 0) {            // prefilter (lx,ly,lz,w)
         host.resize((size_t)n * 4);
         t.count = pbrk_host_prefilter_table(n, roughness, host.data(), &t.alpha);
+        t.weights.resize((size_t)(t.count > 0 ? t.count : 0));
+        for (int i = 0; i < t.count; ++i) t.weights[(size_t)i] = host[(size_t)i * 4 + 3];
     } else if (kind == 1) {     // irradiance
         host.resize((size_t)n * 4);
         t.count = pbrk_host_irradiance_table(n, host.data());
@@ -1140,11 +1147,50 @@ static bool ensure_bordered(TextureImpl* t, hipStream_t st, int first_level = 0)
     }
     // only the levels somebody samples get an apron: the precompute never touches level 0 of its source (400 MB at 2048^2)
     int end = t->bordered_valid ? t->bordered_from : levels;
-    if (!t->bordered_valid) for (char& v : t->cells_valid) v = 0;
+    if (!t->bordered_valid) { for (char& v : t->cells_valid) v = 0; for (char& v : t->range_valid) v = 0; }
     int rc = pbrk_border_build_range(t->dev, t->bordered, W, levels, first_level, end, st);
     if (rc != PBRK_OK) { gpu_fail("border build failed (%d)", rc); return false; }
     t->bordered_valid = true; t->bordered_from = first_level;
     return true;
+}
+
+// {min, max} of the RGB values of level l (blocking: one reduction + an 8-byte read-back per level and content change)
+static bool level_range(TextureImpl* t, int l, hipStream_t st, float* mn, float* mx) {
+    const int levels = (int)t->base.mip_level_count;
+    if (t->range_valid.empty()) { t->range_valid.assign((size_t)levels, 0); t->range_min.assign((size_t)levels, 0.0f); t->range_max.assign((size_t)levels, 0.0f); }
+    if (!t->range_valid[(size_t)l]) {
+        if (!t->range_dev && hipMalloc(&t->range_dev, 8) != hipSuccess) { t->range_dev = nullptr; return false; }
+        const unsigned init[2] = {0x7F800000u, 0u};
+        unsigned got[2] = {0, 0};
+        HIP_OK(hipMemcpyAsync(t->range_dev, init, 8, hipMemcpyHostToDevice, st));
+        const size_t n = mip_dim(t->base.width, (uint32_t)l);
+        if (pbrk_level_minmax((const char*)t->dev + t->mip_offset[(size_t)l], 6 * n * n, t->range_dev, st) != PBRK_OK) return false;
+        HIP_OK(hipMemcpyAsync(got, t->range_dev, 8, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        memcpy(&t->range_min[(size_t)l], &got[0], 4); memcpy(&t->range_max[(size_t)l], &got[1], 4);
+        t->range_valid[(size_t)l] = 1;
+    }
+    *mn = t->range_min[(size_t)l]; *mx = t->range_max[(size_t)l];
+    return true;
+}
+// Samples a prefilter dispatch keeps under GPUX_SetPrefilterTolerance(rel): the smallest prefix K of the weight table (weights fall
+// with the sample index) with  tail(K) * max <= rel * head(K) * min.  Every tap is a convex combination of the level's texels, so a
+// texel's dropped part is at most tail * max and what it keeps at least head * min: `rel` bounds the relative error of every
+// texel and channel.  Sums in double, from the tail so that the small terms are not lost.
+static int bounded_sample_count(const DeviceTable* tab, float mn, float mx, float rel) {
+    const int n = tab->count;
+    if (!(rel > 0.0f) || n < 2 || !(mn > 0.0f) || !(mx >= mn) || !isfinite(mx) || (int)tab->weights.size() != n) return n;
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) total += (double)tab->weights[(size_t)i];
+    double tail = 0.0;
+    int K = n;
+    for (int i = n - 1; i >= 1; --i) {                      // try K = i: drop samples i .. n-1
+        const double t2 = tail + (double)tab->weights[(size_t)i];
+        const double head = total - t2;
+        if (!(t2 * (double)mx <= (double)rel * head * (double)mn)) break;
+        tail = t2; K = i;
+    }
+    return K;
 }
 
 // cells twin of one level (needs a valid bordered twin); NULL when the level is too big to be worth it (n > 512)
@@ -1296,9 +1342,15 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
             if (cells_ready(et, l)) cells = ensure_cells(et, l, st);
             else { timed(g, "cells.env", ev_used, [&] { cells = ensure_cells(et, l, st); }); publish_side_work(g); }
         }
+        int n_keep = tab ? tab->count : 0;
+        if (!copy && op.cpipe->kernel == Kernel_Prefilter && G.prefilter_tol > 0.0f) {         // opt-in: tolerance-budgeted sample cut (gpux.h)
+            float mn = 0.0f, mx = 0.0f;
+            if (level_range(et, l, st, &mn, &mx)) n_keep = bounded_sample_count(tab, mn, mx, G.prefilter_tol);
+        }
+        if (!copy && op.cpipe->kernel == Kernel_Prefilter && c.mip_level >= 0 && c.mip_level < 32) G.kept_samples[c.mip_level] = n_keep;
         timed(g, nm, ev_used, [&] {
             int rc = copy ? pbrk_prefilter_copy(src, n_src, out_ptr, (int)size, (int)op.face0, (int)op.face1, (int)op.row0, (int)op.row1, st)
-                          : pbrk_mc_filter(src, cells, n_src, tab->dev, tab->count, divisor, alpha, out_ptr, (int)size,
+                          : pbrk_mc_filter(src, cells, n_src, tab->dev, n_keep, divisor, alpha, out_ptr, (int)size,
                                            (int)op.face0, (int)op.face1, (int)op.row0, (int)op.row1, st);
             if (rc != PBRK_OK) gpu_fail("%s launch failed (%d)", nm, rc);
         });
@@ -1734,3 +1786,5 @@ GPU_API uint32_t GPUX_GraphTimedOpCount(GPU_Graph* g) { return g ? (uint32_t)g->
 GPU_API const char* GPUX_GraphTimedOpName(GPU_Graph* g, uint32_t i) { return (g && i < g->timed_names.size()) ? g->timed_names[i].c_str() : ""; }
 GPU_API float GPUX_GraphTimedOpMs(GPU_Graph* g, uint32_t i) { return (g && i < g->timed_ms.size()) ? g->timed_ms[i] : 0.0f; }
 GPU_API float GPUX_GraphSpanMs(GPU_Graph* g) { return g ? g->span_ms : 0.0f; }
+GPU_API void GPUX_SetPrefilterTolerance(float rel) { G.prefilter_tol = rel > 0.0f ? rel : 0.0f; }
+GPU_API int GPUX_PrefilterKeptSamples(uint32_t mip) { return mip < 32 ? G.kept_samples[mip] : 0; }

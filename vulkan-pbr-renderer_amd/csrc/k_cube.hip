@@ -211,6 +211,28 @@ __global__ __launch_bounds__(256) void k_prefilter_copy_general(const float4* __
     out[((size_t)f * size + y) * size + x] = v;
 }
 
+// Smallest and largest RGB value of one level (non-negative inputs; anything negative or NaN reports a minimum of 0): the dynamic
+// range the tolerance-budgeted sample cut of K4b needs (gpu_hip.cpp, GPUX_SetPrefilterTolerance).  out2 = {min bits, max bits},
+// initialised by the caller to {+inf, 0}; non-negative floats order like their bit patterns.
+__global__ __launch_bounds__(256) void k_level_minmax(const float4* __restrict__ lvl, size_t n, unsigned* __restrict__ out2) {
+    float mn = __uint_as_float(0x7F800000u), mx = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float4 v = lvl[i];
+        mn = fminf(mn, fmaxf(fminf(fminf(v.x, v.y), v.z), 0.0f));
+        mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), v.z));
+        if (!(v.x >= 0.0f) || !(v.y >= 0.0f) || !(v.z >= 0.0f)) mn = 0.0f;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&out2[0], __float_as_uint(mn)); atomicMax(&out2[1], __float_as_uint(fmaxf(mx, 0.0f))); }
+}
+extern "C" int pbrk_level_minmax(const void* level, size_t texels, void* out2_device, void* stream) {
+    if (!level || !texels || !out2_device) return PBRK_E_ARG;
+    size_t blocks = (texels + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_level_minmax, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)level, texels, (unsigned*)out2_device);
+    return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+}
+
 // Cube-sampler convention switch: 0 = exact fp32 tap weights (default, every fast kernel), 1 = coordinates and
 // LOD fraction snapped to 1/256 texel.  With the switch on, K3 / K4 / K5 run their general kernels (the fast ones implement the
 // default convention only): a diagnostic to MEASURE how far the outputs move between two conventions the reference permits.

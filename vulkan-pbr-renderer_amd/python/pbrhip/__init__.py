@@ -219,6 +219,8 @@ PROTOTYPES = {
     "pbrk_host_sample_angles": (None, [C.c_int, VP]), "pbrk_host_prefilter_table": (C.c_int, [C.c_int, C.c_float, VP, C.POINTER(C.c_float)]),
     "pbrk_host_irradiance_table": (C.c_int, [C.c_int, VP]),
     "pbrk_mip_chain": (C.c_int, [VP, C.c_int, C.c_int, VP]),
+    "pbrk_level_minmax": (C.c_int, [VP, C.c_size_t, VP, VP]),
+    "GPUX_SetPrefilterTolerance": (None, [C.c_float]), "GPUX_PrefilterKeptSamples": (C.c_int, [U32]),
     "pbrk_set_cube_sampler_snap": (None, [C.c_int]), "pbrk_get_cube_sampler_snap": (C.c_int, []), "pbrk_box_downsample": (C.c_int, [VP, C.c_int, VP, C.c_int, VP]),
     "pbrk_blit_linear": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_int, VP]),
     "pbrk_border_build": (C.c_int, [VP, VP, C.c_int, C.c_int, VP]),
