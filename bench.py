@@ -619,6 +619,29 @@ def main():
             L.PBR_RecordUnits(pipes, graph, arena, env_tex, C.byref(maps), one, n_one)
             L.GPU_GraphSubmit(graph); L.GPU_GraphWait(graph); L.GPU_ResetDescriptorArena(arena)
             extra["check_gather_equals_single_gpu"] = bool(torch.equal(gathered, spec_mem))
+        if world == 1:
+            # How far does the job move between the two cube-sampler conventions the reference permits?  The same job once more
+            # with tap coordinates snapped to 1/256 texel (general kernels), against the exact-weight result above; the exact maps are restored.
+            try:
+                exact_spec, exact_irr = spec_mem.clone(), irr_mem.clone()
+                L.pbrk_set_cube_sampler_snap(1)
+                step(); sync()
+                delta = {}
+                for mip in range(min(n_mips, 5)):
+                    size = max(1, spec_size >> mip)
+                    off = L.pbrk_level_offset(spec_size, mip) * 4
+                    a = spec_mem[off: off + 6 * size * size * 4].view(-1, 4)[:, :3].double(); b = exact_spec[off: off + 6 * size * size * 4].view(-1, 4)[:, :3].double()
+                    e = (a - b).abs() / torch.clamp(b.abs(), min=1e-3)
+                    delta[f"prefilter_mip{mip}"] = {"max_rel": float(e.max().item()), "rms_rel": float(e.pow(2).mean().sqrt().item())}
+                a = irr_mem.view(-1, 4)[:, :3].double(); b = exact_irr.view(-1, 4)[:, :3].double()
+                e = (a - b).abs() / torch.clamp(b.abs(), min=1e-3)
+                delta["irradiance"] = {"max_rel": float(e.max().item()), "rms_rel": float(e.pow(2).mean().sqrt().item())}
+                extra["check_sampler_convention_delta"] = delta
+            except Exception as e:
+                extra["check_sampler_convention_delta_error"] = repr(e)
+            finally:
+                L.pbrk_set_cube_sampler_snap(0)
+                step(); sync()
 
     # SURVEY 8(d) headline rates of the whole job (all ranks): Monte-Carlo texels only, sample evaluations, algorithmic bytes
     mc_texels = sum(6 * max(1, spec_size >> m) ** 2 for m in range(1, n_mips)) + 6 * irr_size * irr_size
