@@ -90,6 +90,12 @@ __global__ __launch_bounds__(256) void k_loads(const void* cells, int bytes, flo
             acc += (a.x ^ a.w) + (a.y ^ a.z);
         } else if (MODE == 5) {
             acc += __builtin_amdgcn_raw_buffer_load_b32(r, cell * 64 + rot, 0, 0);
+        } else if (MODE == 11) {                           // SoA cells: piece k of every cell in its own plane (16 B per cell and plane)
+            const int plane = NC * NC * 16;
+            int off = cell * 16 + (it & 7) * NC * 16;
+            u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(r, off, plane, 0),
+                  c = __builtin_amdgcn_raw_buffer_load_b128(r, off, 2 * plane, 0);
+            acc += (a.x ^ b.y ^ c.z) + (a.y ^ b.z ^ c.w) + (a.z ^ b.w ^ c.x) + (a.w ^ b.x ^ c.y);
         } else if (MODE == 8) {                            // coalesced: 64 lanes x 4 B = 256 contiguous bytes (a G-buffer plane of 64 pixels)
             acc += __builtin_amdgcn_raw_buffer_load_b32(r, ((blockIdx.x * 4 + wv) % 512) * 4096 + lane * 4 + rot, 0, 0);
         } else if (MODE == 9) {                            // coalesced: 64 lanes x 16 B = 1 KB contiguous (4 pixels of a plane per lane)
@@ -154,10 +160,10 @@ int main() {
                    ms * 1e-3 * 2.4e9 * 256 / wave_iters);
         }
     }
-    const char* ln[11] = {"3 scattered x4 (48 B cells)", "3 scattered x4 (64 B cells)", "4 quad-coop x4 + LDS", "3 coherent x4", "1 scattered x4", "1 scattered dword", "4 quad-coop x4, no LDS", "4 tri-coop x4 (48 B cells) + LDS",
-                          "1 coalesced dword (256 B / wave)", "1 coalesced dwordx4 (1 KB / wave)", "1 coalesced dwordx2 (512 B / wave)"};
-    for (int window : {21, 9}) {
-        for (int mode = 0; mode < 11; ++mode) {
+    const char* ln[12] = {"3 scattered x4 (48 B cells)", "3 scattered x4 (64 B cells)", "4 quad-coop x4 + LDS", "3 coherent x4", "1 scattered x4", "1 scattered dword", "4 quad-coop x4, no LDS", "4 tri-coop x4 (48 B cells) + LDS",
+                          "1 coalesced dword (256 B / wave)", "1 coalesced dwordx4 (1 KB / wave)", "1 coalesced dwordx2 (512 B / wave)", "3 scattered x4, SoA planes"};
+    for (int window : {21, 13, 9}) {
+        for (int mode = 0; mode < 12; ++mode) {
             float ms = 0; const int iters = 256, lb = 256 * 8 * 2;
             for (int rep = 0; rep < 3; ++rep) {
                 hipEventRecord(e0);
@@ -172,6 +178,7 @@ int main() {
                 case 8: hipLaunchKernelGGL(k_loads<8>, dim3(lb), dim3(256), 0, 0, d, bytes, o, window, iters); break;
                 case 9: hipLaunchKernelGGL(k_loads<9>, dim3(lb), dim3(256), 0, 0, d, bytes, o, window, iters); break;
                 case 10: hipLaunchKernelGGL(k_loads<10>, dim3(lb), dim3(256), 0, 0, d, bytes, o, window, iters); break;
+                case 11: hipLaunchKernelGGL(k_loads<11>, dim3(lb), dim3(256), 0, 0, d, bytes, o, window, iters); break;
                 default: hipLaunchKernelGGL(k_loads<6>, dim3(lb), dim3(256), 0, 0, d, bytes, o, window, iters); break;
                 }
                 hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
