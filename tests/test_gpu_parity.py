@@ -94,6 +94,49 @@ def test_mip_chain_of_faces_that_are_not_a_power_of_two(gpu, W):
     L.GPU_DestroyGraph(g); L.GPU_DestroyTexture(tex)
 
 
+def test_linear_blit_between_rectangles_and_equirect_cube_of_any_size(gpu):
+    """The linear resample of GPU_OpBlit beyond mip chains: whole RGBA32F 2-D subresources of unrelated sizes (37 x 21 -> 16 x 9 down,
+    5 x 3 -> 12 x 8 up: clamp to edge) equal the oracle's rule bit for bit; and the equirect loader builds a 96^2 cube (restriction to
+    powers of two lifted) whose levels 96 .. 1 equal the oracle's chain of its level 0."""
+    import pbrhip, pbr_oracle as O
+    L = gpu
+    rng = np.random.default_rng(0x5EED00C7)
+
+    class Off(C.Structure):
+        _fields_ = [("x", C.c_int), ("y", C.c_int), ("z", C.c_int)]
+
+    class Blit(C.Structure):                    # GPU_OpBlitInfo [gpu.h:317-327]
+        _fields_ = [("filter", C.c_int), ("src_texture", pbrhip.TexP), ("dst_texture", pbrhip.TexP), ("src_layer", C.c_uint32), ("dst_layer", C.c_uint32),
+                    ("src_mip_level", C.c_uint32), ("dst_mip_level", C.c_uint32), ("src_area", Off * 2), ("dst_area", Off * 2)]
+    g = L.GPU_MakeGraph()
+    for (sw, sh, dw, dh) in ((37, 21, 16, 9), (5, 3, 12, 8), (64, 64, 64, 17)):
+        src = (rng.random((sh, sw, 4), dtype=np.float32) * 9.0).astype(np.float32)
+        ts = pbrhip.make_texture(pbrhip.Format_RGBA32F, sw, sh, pbrhip.TextureFlag_RenderTarget)
+        td = pbrhip.make_texture(pbrhip.Format_RGBA32F, dw, dh, pbrhip.TextureFlag_RenderTarget)
+        pbrhip.upload_mip(ts, 0, src)
+        b = Blit(); b.filter = 0; b.src_texture = ts; b.dst_texture = td
+        b.src_area[1] = Off(sw, sh, 1); b.dst_area[1] = Off(dw, dh, 1)
+        L.GPU_OpBlit(g, C.byref(b)); L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+        got = pbrhip.read_mip(td, 0)
+        want = O.blit_linear(src[None], dw, dh)[0]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (sw, sh, dw, dh)
+        L.GPU_DestroyTexture(ts); L.GPU_DestroyTexture(td)
+    L.GPU_DestroyGraph(g)
+    h, w = 64, 128
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    pano = np.ones((h, w, 4), np.float32)
+    pano[..., 0] = 0.5 + 0.4 * np.sin(xx * 2 * np.pi / w * 3); pano[..., 1] = 0.2 + yy / h; pano[..., 2] = rng.random((h, w)).astype(np.float32)
+    tex = L.GPUX_MakeCubemapFromEquirect(pano.ctypes.data_as(C.c_void_p), w, h, 96, 0)
+    assert tex and tex.contents.width == 96 and tex.contents.mip_level_count == 7
+    l0 = pbrhip.read_mip(tex, 0)
+    want0 = O.equirect_to_cube(pano, 96)
+    assert (np.abs(l0.astype(np.float64) - want0) / np.maximum(np.abs(want0), 1e-3)).max() < 1e-4
+    pyr = O.build_pyramid(l0)
+    for m in range(7):
+        assert np.array_equal(pbrhip.read_mip(tex, m).view(np.uint32), O.pyramid_level(pyr, 96, m).view(np.uint32)), m
+    L.GPU_DestroyTexture(tex)
+
+
 def test_precompute_from_an_environment_that_is_not_a_power_of_two(gpu):
     """The whole precompute from a 96^2 HDR cube (levels 96 .. 1): K4a copies from the 48^2 level, K4b filters the 12^2, 6^2, 3^2
     levels, K3 the 1^2 level -- source sizes none of the power-of-two tests reach -- vs the oracle at 1e-4."""
