@@ -197,6 +197,9 @@ def main():
                     help="record the job as two graphs (mip-1 units first) and send each part while the next computes (PBR_RunPartitionedIBL; "
                          "needs the C gather for N > 1; opt-in: never run on more than one GPU)")
     ap.add_argument("--check", action="store_true", help="after the run, spot-check output texels against the oracle")
+    ap.add_argument("--bounded-cut", action="store_true",
+                    help="also time the job with the opt-in tolerance-budgeted sample cut (GPUX_SetPrefilterTolerance(1e-7)) -> extra.c4_bounded_cut; "
+                         "off by default so that a kernel trace of the default command holds the exact kernels only")
     ap.add_argument("--hdr", default=None, metavar="FILE.hdr",
                     help="real environment instead of the synthetic one: a Radiance .hdr cube strip (height == 6 x width, the reference's "
                          "layout, asset_import.cpp:17-27 -> PBR_MakeTextureFromHDRIFile) or an equirectangular panorama (width == 2 x "
@@ -565,7 +568,7 @@ def main():
         if rank == 0:
             extra["shade_c5"] = c5
 
-    if rank == 0 and world == 1 and not args.no_shade:
+    if rank == 0 and world == 1 and args.bounded_cut:
         # NOT the headline and never the default (the reference sums every sample): the same job with the tolerance-budgeted sample cut
         # (GPUX_SetPrefilterTolerance(1e-7): a rigorous per-texel bound from the weight table and each source level's measured range)
         try:

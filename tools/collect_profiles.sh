@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 cd /tmp                                        # rocprofv3 scratch files go to the working directory
 B=$REPO/bench.py
 
-python3 $B > "$OUT/${TAG}_bench.json"
+python3 $B --bounded-cut > "$OUT/${TAG}_bench.json"
 echo "[1/6] bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$SCR/kt" -- python3 $B --no-cpu-baseline > "$OUT/${TAG}_bench_under_rocprof.json"
 echo "[2/6] kernel trace done"

@@ -301,7 +301,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const int q8 = t >> 6, l8 = t & 63;
     const int x = tx * TILE + (q8 & 1) * 8 + (l8 & 7);
     const int y = p.y0 + ty * TILE + (q8 >> 1) * 8 + (l8 >> 3);
-    const bool valid = (x < p.size) && (y < p.y0 + p.rows);
     const int xc = min(x, p.size - 1), yc = min(y, p.y0 + p.rows - 1);
 
     const f3 R = face_texel_dir(face, xc, yc, p.size);
@@ -402,10 +401,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         }
         __syncthreads();
     }
-    if (valid && s == 0) {
+    // The texel's coordinates are formed AGAIN from the thread index (opaque to the optimiser) instead of being kept alive across
+    // the passes: at the 64-VGPR budget the quarter-face instantiation otherwise spills them (4 VGPRs, 16 bytes of scratch per lane
+    // and tile: harmless in time, but rocprofv3's WRITE_SIZE of C4 mip 1 read 853 MB against 403 MB of output).
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
+    const int t_o = tid_o % REG_TX, q8_o = t_o >> 6, l8_o = t_o & 63;
+    const int x_o = tx * TILE + (q8_o & 1) * 8 + (l8_o & 7);
+    const int y_o = p.y0 + ty * TILE + (q8_o >> 1) * 8 + (l8_o >> 3);
+    if (x_o < p.size && y_o < p.y0 + p.rows && s == 0) {
         float4 o;
-        o.x = red[t * 3 + 0] / p.divisor; o.y = red[t * 3 + 1] / p.divisor; o.z = red[t * 3 + 2] / p.divisor; o.w = p.alpha;
-        p.out[((size_t)face * p.size + y) * p.size + x] = o;
+        o.x = red[t_o * 3 + 0] / p.divisor; o.y = red[t_o * 3 + 1] / p.divisor; o.z = red[t_o * 3 + 2] / p.divisor; o.w = p.alpha;
+        p.out[((size_t)face * p.size + y_o) * p.size + x_o] = o;
     }
 }
 
