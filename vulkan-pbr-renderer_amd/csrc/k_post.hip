@@ -21,6 +21,9 @@ namespace {
 __device__ __forceinline__ float h2f(unsigned short h) { return __half2float(__ushort_as_half(h)); }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ float lerpx(float p, float q, float t) { return p + t * (q - p); }
+// The same value for a COMPILE-TIME fraction: when t is a power of two, t * (q - p) is exact (texels are fp16: no fp32 underflow within
+// reach), so one FMA rounds exactly like the multiply-add pair; other fractions keep the sampler's two roundings.
+__device__ __forceinline__ float lerpc(float p, float q, float t) { return (t == 0.5f || t == 0.25f) ? fmaf(t, q - p, p) : p + t * (q - p); }
 
 struct Rgba { float x, y, z, w; };
 
@@ -311,6 +314,57 @@ __global__ __launch_bounds__(256) void k_final_post_process_stream(PbrkFinalArgs
 struct BloomParams { PbrkBloomArgs a; float x_step, y_step, rcp_dw, rcp_dh; int exact2to1; };
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
+// The general path of a bloom pass: every tap through the snapped bilinear sampler (any size ratio, border pixels of the exact passes).
+template <bool kUp>
+__device__ __forceinline__ void bloom_general(const BloomParams& P, const __amdgpu_buffer_rsrc_t rs, const int px, const int py, float* r) {
+    const PbrkBloomArgs& A = P.a;
+    const int SW = A.src.width, SH = A.src.height;
+    SharedRcp rw, rh;
+    rw.d = (float)A.dst_width; rw.r = P.rcp_dw; rh.d = (float)A.dst_height; rh.r = P.rcp_dh;
+    const float u = div_by((float)px + 0.5f, rw), v = div_by((float)py + 0.5f, rh);       // fs_uv (full-screen triangle)
+    constexpr int kOffs = kUp ? 3 : 5;                                                  // offsets -1..1 (x radius) or -2..2 (x texel)
+    int ci0[kOffs], ci1[kOffs], cj0[kOffs], cj1[kOffs]; float ca[kOffs], cb[kOffs];
+#pragma unroll
+    for (int k = 0; k < kOffs; ++k) {
+        const float off = (float)(k - kOffs / 2);
+        split_axis(u + off * P.x_step, SW, ci0[k], ci1[k], ca[k]);
+        split_axis(v + off * P.y_step, SH, cj0[k], cj1[k], cb[k]);
+    }
+    auto tap = [&](int kx, int ky, float* o) {
+        Rgba t00 = fetch_rgba16f(rs, SW, ci0[kx], cj0[ky]), t10 = fetch_rgba16f(rs, SW, ci1[kx], cj0[ky]);
+        Rgba t01 = fetch_rgba16f(rs, SW, ci0[kx], cj1[ky]), t11 = fetch_rgba16f(rs, SW, ci1[kx], cj1[ky]);
+        o[0] = lerpx(lerpx(t00.x, t10.x, ca[kx]), lerpx(t01.x, t11.x, ca[kx]), cb[ky]);
+        o[1] = lerpx(lerpx(t00.y, t10.y, ca[kx]), lerpx(t01.y, t11.y, ca[kx]), cb[ky]);
+        o[2] = lerpx(lerpx(t00.z, t10.z, ca[kx]), lerpx(t01.z, t11.z, ca[kx]), cb[ky]);
+    };
+    if (kUp) {                                                                          // bloom_upsample.glsl:43-58
+        float t[9][3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) tap(k % 3, k / 3, t[k]);                            // a b c / d e f / g h i
+        const float factor = A.dst_mip_level == 0 ? 0.06f : 1.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float sum = t[4][c] * 4.0f;
+            sum = sum + (((t[1][c] + t[3][c]) + t[5][c]) + t[7][c]) * 2.0f;
+            sum = sum + (((t[0][c] + t[2][c]) + t[6][c]) + t[8][c]);
+            r[c] = sum * factor / 16.0f;
+        }
+    } else {                                                                            // bloom_downsample.glsl:50-97
+        float t[13][3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) tap(2 * (k % 3), 2 * (k / 3), t[k]);                // a..i at offsets -2, 0, 2
+        tap(1, 1, t[9]); tap(3, 1, t[10]); tap(1, 3, t[11]); tap(3, 3, t[12]);          // j k l m at (+-1, +-1)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float sum = t[4][c] * 0.125f;
+            sum = sum + (((t[0][c] + t[2][c]) + t[6][c]) + t[8][c]) * 0.03125f;
+            sum = sum + (((t[1][c] + t[3][c]) + t[5][c]) + t[7][c]) * 0.0625f;
+            sum = sum + (((t[9][c] + t[10][c]) + t[11][c]) + t[12][c]) * 0.125f;
+            if (A.dst_mip_level == 1) sum = fminf(sum, 1.0f);
+            r[c] = sum;
+        }
+    }
+}
 template <bool kUp>
 __global__ __launch_bounds__(256) void k_bloom_pass(BloomParams P) {
     const PbrkBloomArgs& A = P.a;
@@ -341,9 +395,9 @@ __global__ __launch_bounds__(256) void k_bloom_pass(BloomParams P) {
 #pragma unroll
                     for (int k = 0; k < 5; ++k)
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) hx[rr][k][c] = lerpx(t[k][c], t[k + 1][c], 0.5f);
+                        for (int c = 0; c < 3; ++c) hx[rr][k][c] = lerpc(t[k][c], t[k + 1][c], 0.5f);
                 }
-                auto tapd = [&](int kx, int ky, int c) { return lerpx(hx[ky][kx][c], hx[ky + 1][kx][c], 0.5f); };
+                auto tapd = [&](int kx, int ky, int c) { return lerpc(hx[ky][kx][c], hx[ky + 1][kx][c], 0.5f); };
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     float sum = tapd(2, 2, c) * 0.125f;
@@ -395,59 +449,150 @@ __global__ __launch_bounds__(256) void k_bloom_pass(BloomParams P) {
             }
         }
     }
-    if (!done) {
-    SharedRcp rw, rh;
-    rw.d = (float)A.dst_width; rw.r = P.rcp_dw; rh.d = (float)A.dst_height; rh.r = P.rcp_dh;
-    const float u = div_by((float)px + 0.5f, rw), v = div_by((float)py + 0.5f, rh);       // fs_uv (full-screen triangle)
-    constexpr int kOffs = kUp ? 3 : 5;                                                  // offsets -1..1 (x radius) or -2..2 (x texel)
-    int ci0[kOffs], ci1[kOffs], cj0[kOffs], cj1[kOffs]; float ca[kOffs], cb[kOffs];
-#pragma unroll
-    for (int k = 0; k < kOffs; ++k) {
-        const float off = (float)(k - kOffs / 2);
-        split_axis(u + off * P.x_step, SW, ci0[k], ci1[k], ca[k]);
-        split_axis(v + off * P.y_step, SH, cj0[k], cj1[k], cb[k]);
-    }
-    auto tap = [&](int kx, int ky, float* o) {
-        Rgba t00 = fetch_rgba16f(rs, SW, ci0[kx], cj0[ky]), t10 = fetch_rgba16f(rs, SW, ci1[kx], cj0[ky]);
-        Rgba t01 = fetch_rgba16f(rs, SW, ci0[kx], cj1[ky]), t11 = fetch_rgba16f(rs, SW, ci1[kx], cj1[ky]);
-        o[0] = lerpx(lerpx(t00.x, t10.x, ca[kx]), lerpx(t01.x, t11.x, ca[kx]), cb[ky]);
-        o[1] = lerpx(lerpx(t00.y, t10.y, ca[kx]), lerpx(t01.y, t11.y, ca[kx]), cb[ky]);
-        o[2] = lerpx(lerpx(t00.z, t10.z, ca[kx]), lerpx(t01.z, t11.z, ca[kx]), cb[ky]);
-    };
-    if (kUp) {                                                                          // bloom_upsample.glsl:43-58
-        float t[9][3];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) tap(k % 3, k / 3, t[k]);                            // a b c / d e f / g h i
-        const float factor = A.dst_mip_level == 0 ? 0.06f : 1.0f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float sum = t[4][c] * 4.0f;
-            sum = sum + (((t[1][c] + t[3][c]) + t[5][c]) + t[7][c]) * 2.0f;
-            sum = sum + (((t[0][c] + t[2][c]) + t[6][c]) + t[8][c]);
-            r[c] = sum * factor / 16.0f;
-        }
-    } else {                                                                            // bloom_downsample.glsl:50-97
-        float t[13][3];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) tap(2 * (k % 3), 2 * (k / 3), t[k]);                // a..i at offsets -2, 0, 2
-        tap(1, 1, t[9]); tap(3, 1, t[10]); tap(1, 3, t[11]); tap(3, 3, t[12]);          // j k l m at (+-1, +-1)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float sum = t[4][c] * 0.125f;
-            sum = sum + (((t[0][c] + t[2][c]) + t[6][c]) + t[8][c]) * 0.03125f;
-            sum = sum + (((t[1][c] + t[3][c]) + t[5][c]) + t[7][c]) * 0.0625f;
-            sum = sum + (((t[9][c] + t[10][c]) + t[11][c]) + t[12][c]) * 0.125f;
-            if (A.dst_mip_level == 1) sum = fminf(sum, 1.0f);
-            r[c] = sum;
-        }
-    }
-    }   // general path
+    if (!done) bloom_general<kUp>(P, rs, px, py, r);
     uint2* o = (uint2*)A.dst + (size_t)py * A.dst_width + px;
     if (A.blend_additive) {
         Rgba d = unpack_rgba16f(*o);
         r[0] = r[0] + d.x; r[1] = r[1] + d.y; r[2] = r[2] + d.z;
     }
     *o = pack_half4(r[0], r[1], r[2]);
+}
+
+// N consecutive texels (rgb) of row y starting at column x0: whole-row loads when the run lies inside the level, else texel by texel
+// with the sampler's clamp to edge (a tap whose two texels clamp to the same one returns it whatever its fraction: p + t (p - p)).
+template <int N>
+__device__ __forceinline__ void bloom_row(const __amdgpu_buffer_rsrc_t rs, const int SW, const int SH, const int x0, const int y, const bool inside, float (*t)[3]) {
+    static_assert(N == 5 || N == 8, "window width");
+    if (inside) {
+        const int off = (y * SW + x0) * 8;
+        unsigned w[16];
+        u32x4v q0 = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0), q1 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 0);
+        w[0] = q0.x; w[1] = q0.y; w[2] = q0.z; w[3] = q0.w; w[4] = q1.x; w[5] = q1.y; w[6] = q1.z; w[7] = q1.w;
+        if (N == 5) { u32x2v q2 = __builtin_amdgcn_raw_buffer_load_b64(rs, off + 32, 0, 0); w[8] = q2.x; w[9] = q2.y; }
+        else {
+            u32x4v q2 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 32, 0, 0), q3 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 48, 0, 0);
+            w[8] = q2.x; w[9] = q2.y; w[10] = q2.z; w[11] = q2.w; w[12] = q3.x; w[13] = q3.y; w[14] = q3.z; w[15] = q3.w;
+        }
+#pragma unroll
+        for (int c = 0; c < N; ++c) { t[c][0] = h2f(w[2 * c] & 0xffff); t[c][1] = h2f(w[2 * c] >> 16); t[c][2] = h2f(w[2 * c + 1] & 0xffff); }
+    } else {
+        const int yc = clampi(y, 0, SH - 1);
+#pragma unroll
+        for (int c = 0; c < N; ++c) { const Rgba v = fetch_rgba16f(rs, SW, clampi(x0 + c, 0, SW - 1), yc); t[c][0] = v.x; t[c][1] = v.y; t[c][2] = v.z; }
+    }
+}
+
+// K10 / K11, exact 2:1 passes of LARGE levels: one thread per 2 x 2 block of target pixels.
+//   up:   the four pixels (2i + ox, 2j + oy) read the SAME 5 x 5 source window around texel (i, j); only their tap fractions differ
+//         (1/4 or 3/4 by parity): 15 loads and 75 conversions per four pixels instead of per pixel.
+//   down: the four pixels share an 8 x 8 source window, and 27 of their 4 x 13 taps coincide (a pixel's tap two texels to the right
+//         is its neighbour's centre tap): 32 loads instead of 72, 25 distinct taps instead of 52.
+// Every tap is the same lerp of the same texels with the same fraction as in k_bloom_pass, and every pixel's sum runs in the
+// shader's order: bit-identical (tests/test_post.py compares all twelve targets with the shader text at 1920 x 1080).
+// Blocks at the border of the level read their window texel by texel with the sampler's edge clamp (the closed-form fractions hold for
+// every pixel; only the whole-row loads need the window inside the level).  Small levels stay with one pixel per thread: they are
+// latency-bound and a four-pixel thread is four times as long.
+template <bool kUp>
+__global__ __launch_bounds__(256) void k_bloom_quad(BloomParams P) {
+    const PbrkBloomArgs& A = P.a;
+    const int qx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int qy = (A.y0 >> 1) + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (2 * qx >= A.dst_width || 2 * qy >= A.y1) return;
+    const int SW = A.src.width, SH = A.src.height;
+    const __amdgpu_buffer_rsrc_t rs = tex_rsrc(A.src, 8);
+    float r[2][2][3];                                                                   // [oy][ox][rgb]
+    const bool interior = kUp ? (qx >= 2 && qx <= SW - 3 && qy >= 2 && qy <= SH - 3)
+                              : (qx >= 1 && 2 * qx + 1 <= A.dst_width - 2 && qy >= 1 && 2 * qy + 1 <= A.dst_height - 2);
+    if (kUp) {
+        // horizontal taps of a row: [parity][left, centre, right]
+        float hx[5][2][3][3];
+#pragma unroll
+        for (int rr = 0; rr < 5; ++rr) {
+            float t[5][3];
+            bloom_row<5>(rs, SW, SH, qx - 2, qy - 2 + rr, interior, t);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                hx[rr][0][0][c] = lerpc(t[0][c], t[1][c], 0.25f); hx[rr][1][0][c] = lerpc(t[0][c], t[1][c], 0.75f);
+                hx[rr][0][1][c] = lerpc(t[1][c], t[2][c], 0.75f); hx[rr][1][1][c] = lerpc(t[2][c], t[3][c], 0.25f);
+                hx[rr][0][2][c] = lerpc(t[3][c], t[4][c], 0.25f); hx[rr][1][2][c] = lerpc(t[3][c], t[4][c], 0.75f);
+            }
+        }
+        const float factor = A.dst_mip_level == 0 ? 0.06f : 1.0f;
+#pragma unroll
+        for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+            for (int ox = 0; ox < 2; ++ox) {
+                const float fy_side = oy ? 0.75f : 0.25f, fy_mid = oy ? 0.25f : 0.75f;
+                auto tapu = [&](int kx, int ky, int c) {
+                    if (ky == 0) return lerpc(hx[0][ox][kx][c], hx[1][ox][kx][c], fy_side);
+                    if (ky == 2) return lerpc(hx[3][ox][kx][c], hx[4][ox][kx][c], fy_side);
+                    return lerpc(hx[oy ? 2 : 1][ox][kx][c], hx[oy ? 3 : 2][ox][kx][c], fy_mid);
+                };
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float sum = tapu(1, 1, c) * 4.0f;
+                    sum = sum + (((tapu(1, 0, c) + tapu(0, 1, c)) + tapu(2, 1, c)) + tapu(1, 2, c)) * 2.0f;
+                    sum = sum + (((tapu(0, 0, c) + tapu(2, 0, c)) + tapu(0, 2, c)) + tapu(2, 2, c));
+                    r[oy][ox][c] = sum * factor / 16.0f;
+                }
+            }
+    } else {
+        // E[b][a]: tap at window position (2a, 2b); O[b][a]: tap at (2a + 1, 2b + 1).  Rows stream through: a tap needs two adjacent rows.
+        float E[4][4][3], O[3][3][3], prev[7][3];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            float t[8][3], cur[7][3];
+            bloom_row<8>(rs, SW, SH, 4 * qx - 2, 4 * qy - 2 + rr, interior, t);
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) cur[k][c] = lerpc(t[k][c], t[k + 1][c], 0.5f);
+            if (rr >= 1) {
+                const int wy = rr - 1;                                                  // taps between rows wy and wy + 1
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if ((wy & 1) == 0) {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) E[wy >> 1][a][c] = lerpc(prev[2 * a][c], cur[2 * a][c], 0.5f);
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) O[wy >> 1][a][c] = lerpc(prev[2 * a + 1][c], cur[2 * a + 1][c], 0.5f);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) prev[k][c] = cur[k][c];
+        }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    auto ev = [&](int kx, int ky) { return E[dy + (ky >> 1)][dx + (kx >> 1)][c]; };    // tapd(kx, ky), kx and ky even
+                    auto od = [&](int kx, int ky) { return O[dy + (ky >> 1)][dx + (kx >> 1)][c]; };    // kx and ky odd
+                    float sum = ev(2, 2) * 0.125f;
+                    sum = sum + (((ev(0, 0) + ev(4, 0)) + ev(0, 4)) + ev(4, 4)) * 0.03125f;
+                    sum = sum + (((ev(2, 0) + ev(0, 2)) + ev(4, 2)) + ev(2, 4)) * 0.0625f;
+                    sum = sum + (((od(1, 1) + od(3, 1)) + od(1, 3)) + od(3, 3)) * 0.125f;
+                    if (A.dst_mip_level == 1) sum = fminf(sum, 1.0f);
+                    r[dy][dx][c] = sum;
+                }
+    }
+#pragma unroll
+    for (int oy = 0; oy < 2; ++oy) {
+        uint4* o = (uint4*)((uint2*)A.dst + (size_t)(2 * qy + oy) * A.dst_width + 2 * qx);
+        if (A.blend_additive) {
+            const uint4 d = *o;
+            const Rgba d0 = unpack_rgba16f(make_uint2(d.x, d.y)), d1 = unpack_rgba16f(make_uint2(d.z, d.w));
+            r[oy][0][0] = r[oy][0][0] + d0.x; r[oy][0][1] = r[oy][0][1] + d0.y; r[oy][0][2] = r[oy][0][2] + d0.z;
+            r[oy][1][0] = r[oy][1][0] + d1.x; r[oy][1][1] = r[oy][1][1] + d1.y; r[oy][1][2] = r[oy][1][2] + d1.z;
+        }
+        const uint2 a = pack_half4(r[oy][0][0], r[oy][0][1], r[oy][0][2]), b = pack_half4(r[oy][1][0], r[oy][1][1], r[oy][1][2]);
+        *o = make_uint4(a.x, a.y, b.x, b.y);
+    }
 }
 
 __global__ void k_debug_sample_post(PbrkTex2D t, const float* __restrict__ coords, int count, float4* __restrict__ out) {
@@ -515,6 +660,16 @@ extern "C" int pbrk_bloom_pass(const PbrkBloomArgs* a, void* stream) {
     const bool small = a->src.width <= 8192 && a->src.height <= 8192 && a->dst_width <= 8192 && a->dst_height <= 8192;
     p.exact2to1 = small && (a->upsample ? (a->dst_width == 2 * a->src.width && a->dst_height == 2 * a->src.height)
                                         : (a->src.width == 2 * a->dst_width && a->src.height == 2 * a->dst_height));
+    // 2 x 2 pixels per thread where the level is large enough to fill the chip with such threads (PBR_BLOOM_QUAD_MIN_PIXELS)
+    static long long quad_min = -1;
+    if (quad_min < 0) { const char* e = getenv("PBR_BLOOM_QUAD_MIN_PIXELS"); quad_min = e ? atoll(e) : 100000; }
+    const bool even = !((a->dst_width | a->dst_height | a->y0 | a->y1) & 1) && ((uintptr_t)a->dst & 15) == 0 && ((uintptr_t)a->src.data & 15) == 0;
+    if (p.exact2to1 && even && (long long)a->dst_width * (a->y1 - a->y0) >= quad_min) {
+        dim3 qgrid((a->dst_width / 2 + 63) / 64, ((a->y1 - a->y0) / 2 + 3) / 4);
+        if (a->upsample) hipLaunchKernelGGL((k_bloom_quad<true>), qgrid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((k_bloom_quad<false>), qgrid, dim3(256), 0, (hipStream_t)stream, p);
+        return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+    }
     dim3 grid((a->dst_width + 63) / 64, (a->y1 - a->y0 + 3) / 4), block(256);
     if (a->upsample) hipLaunchKernelGGL((k_bloom_pass<true>), grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((k_bloom_pass<false>), grid, block, 0, (hipStream_t)stream, p);
