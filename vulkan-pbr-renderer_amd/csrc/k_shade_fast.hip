@@ -32,21 +32,13 @@ __device__ __forceinline__ f3 pre_level_fetch(__amdgpu_buffer_rsrc_t rc, float f
     return cells_bilerp(bl4(rc, off), bl4(rc, off + 16), bl4(rc, off + 32), a, b);
 }
 
-// kStride: which pixels share a wave.  1: 64 consecutive pixels of a row (workgroup = 64 x 4 pixels).  9: every 9th pixel of a
-// 576-pixel row segment, the nine waves of a workgroup interleaved (wave j takes x = 9 k + j).  The shader jitters the reflection
-// vector with InterleavedGradientNoise (:119-121, :456-459, :695), fract(52.9829189 fract(.06711056 x + .00583715 y)): one pixel
-// to the right advances the outer argument by 3.5557, nine pixels by 32.0014 -- an integer to 1.4e-3 -- so pixels nine apart get
-// (almost) the same three noise values, hence the same jitter, and their reflection vectors differ by what nine pixels of
-// geometry turn them: half a texel of the prefiltered level instead of the +-6 to 12 texels the jitter spreads neighbours over.
-// The six 16-byte taps of adjacent lanes then fall into the same or adjacent cells (coherent through the texture path); the price
-// is G-buffer loads and stores with a 36- / 72-byte lane pitch, whose lines the nine waves of the workgroup share through L1 / L2.
-template <bool kIBL, bool kShafts, int kStride, bool kTab = false>
-__global__ __launch_bounds__(kStride == 1 ? 256 : 576) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shade_fast(const ShadeParams p) {
+template <bool kIBL, bool kShafts, bool kTab = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shade_fast(const ShadeParams p) {
     __shared__ int lv_off[16];        // byte offset of level l inside the prefiltered cells twin
     if (threadIdx.x < 16) lv_off[threadIdx.x] = cells_level_off(p.pre_size, 0, min((int)threadIdx.x, p.pre_levels - 1)) * 16;
     __syncthreads();
-    const int lx = kStride == 1 ? blockIdx.x * 64 + (threadIdx.x & 63) : blockIdx.x * (64 * kStride) + (threadIdx.x & 63) * kStride + (threadIdx.x >> 6);
-    const int ly = kStride == 1 ? blockIdx.y * 4 + (threadIdx.x >> 6) : blockIdx.y;
+    const int lx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ly = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (lx >= p.w || ly >= p.h) return;
     const int px = p.x0 + lx, py = p.y0 + ly;
     const int pi4 = (py * p.width + px) * 4;                          // all five G-buffer planes hold 4 bytes per pixel
@@ -140,9 +132,10 @@ __global__ __launch_bounds__(kStride == 1 ? 256 : 576) __attribute__((amdgpu_wav
         return mk3(fmaf(w, c1.x - c0.x, c0.x), fmaf(w, c1.y - c0.y, c0.y), fmaf(w, c1.z - c0.z, c0.z));
     };
 
-    if (sky) {                                                                          // :708-710
-        outl = pre_fetch(mk3(-V.x, -V.y, -V.z), 1.0f);
-    } else {
+    f3 fdir = mk3(-V.x, -V.y, -V.z);                                                    // :708-710: a sky pixel shows level 1 along the view ray
+    float flod = 1.0f;
+    f3 fscale = mk3(1.0f, 1.0f, 1.0f);
+    if (!sky) {
         const float dNV = dot3(N, V);                                                   // exact: -dNV is dot(N, I) of :694
         const float VdotN = fmaxf(dNV, 0.0f);                                           // :613
         if (kShafts) {                                                                  // :622-651 with visibility == 1
@@ -212,14 +205,18 @@ __global__ __launch_bounds__(kStride == 1 ? 256 : 576) __attribute__((amdgpu_wav
             R = normalize3_nr(mk3(R.x + jr * (noise_1 - 0.5f), R.y + jr * (noise_2 - 0.5f), R.z + jr * (noise_3 - 0.5f)));
             const float r2 = roughness * roughness, r4 = r2 * r2;
             R = mk3(mix_(R.x, N.x, r4), mix_(R.y, N.y, r4), mix_(R.z, N.z, r4));
-            const f3 spec = pre_fetch(R, roughness * 4.0f);                              // :699
-
-            outl.x = fmaf(spec.x, fmaf(F0.x, sbx, sby), outl.x);                          // :702
-            outl.y = fmaf(spec.y, fmaf(F0.y, sbx, sby), outl.y);
-            outl.z = fmaf(spec.z, fmaf(F0.z, sbx, sby), outl.z);
+            fdir = R; flod = roughness * 4.0f;                                           // :699
+            fscale = mk3(fmaf(F0.x, sbx, sby), fmaf(F0.y, sbx, sby), fmaf(F0.z, sbx, sby));  // :702
         }
-        outl = add3(outl, emissive);                                                    // :706
     }
+    if (kIBL || sky) {
+        // one fetch sequence for sky and surface lanes of a wave (the sky's level-1 lookup along the view ray and the surface's
+        // jittered reflection differ in their operands only)
+        const f3 spec = pre_fetch(fdir, flod);
+        if (sky) outl = spec;
+        else { outl.x = fmaf(spec.x, fscale.x, outl.x); outl.y = fmaf(spec.y, fscale.y, outl.y); outl.z = fmaf(spec.z, fscale.z, outl.z); }
+    }
+    if (!sky) outl = add3(outl, emissive);                                              // :706
     outl = mk3(fmaxf(outl.x, 0.0f), fmaxf(outl.y, 0.0f), fmaxf(outl.z, 0.0f));          // :712
     const size_t pi = (size_t)py * p.width + px;
     if (p.out_fmt == PBRK_FMT_RGBA16F) {
@@ -235,29 +232,22 @@ __global__ __launch_bounds__(kStride == 1 ? 256 : 576) __attribute__((amdgpu_wav
 }
 
 int launch_shade_fast(const ShadeParams& p, bool ibl, bool shafts, hipStream_t stream) {
-    static int stride9 = -1;
-    if (stride9 < 0) { const char* e = getenv("PBR_SHADE_STRIDE9"); stride9 = e ? atoi(e) : 0; }
     // kTab: measured SLOWER than recomputing (8K frame 564-576 vs 540-544 us, 1080p 24.8 vs 23.3 us: 24 fewer VALU instructions do not
     // pay for one more vector-memory instruction per wave -- the kernel is bound by its memory instructions); opt-in
     static int tab = -1;
     if (tab < 0) { const char* e = getenv("PBR_SHADE_TABLES"); tab = e ? atoi(e) : 0; }
     if (tab && p.col_tab && p.row_tab) {
         dim3 grid((p.w + 63) / 64, (p.h + 3) / 4);
-        if (ibl && shafts) hipLaunchKernelGGL((k_shade_fast<true, true, 1, true>), grid, dim3(256), 0, stream, p);
-        else if (ibl) hipLaunchKernelGGL((k_shade_fast<true, false, 1, true>), grid, dim3(256), 0, stream, p);
-        else if (shafts) hipLaunchKernelGGL((k_shade_fast<false, true, 1, true>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((k_shade_fast<false, false, 1, true>), grid, dim3(256), 0, stream, p);
-        return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
-    }
-    if (stride9 && ibl && !shafts) {
-        dim3 grid((p.w + 575) / 576, p.h);
-        hipLaunchKernelGGL((k_shade_fast<true, false, 9>), grid, dim3(576), 0, stream, p);
+        if (ibl && shafts) hipLaunchKernelGGL((k_shade_fast<true, true, true>), grid, dim3(256), 0, stream, p);
+        else if (ibl) hipLaunchKernelGGL((k_shade_fast<true, false, true>), grid, dim3(256), 0, stream, p);
+        else if (shafts) hipLaunchKernelGGL((k_shade_fast<false, true, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((k_shade_fast<false, false, true>), grid, dim3(256), 0, stream, p);
         return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
     }
     dim3 grid((p.w + 63) / 64, (p.h + 3) / 4);
-    if (ibl && shafts) hipLaunchKernelGGL((k_shade_fast<true, true, 1>), grid, dim3(256), 0, stream, p);
-    else if (ibl) hipLaunchKernelGGL((k_shade_fast<true, false, 1>), grid, dim3(256), 0, stream, p);
-    else if (shafts) hipLaunchKernelGGL((k_shade_fast<false, true, 1>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((k_shade_fast<false, false, 1>), grid, dim3(256), 0, stream, p);
+    if (ibl && shafts) hipLaunchKernelGGL((k_shade_fast<true, true>), grid, dim3(256), 0, stream, p);
+    else if (ibl) hipLaunchKernelGGL((k_shade_fast<true, false>), grid, dim3(256), 0, stream, p);
+    else if (shafts) hipLaunchKernelGGL((k_shade_fast<false, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((k_shade_fast<false, false>), grid, dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
