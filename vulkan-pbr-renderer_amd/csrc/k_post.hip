@@ -19,7 +19,13 @@
 namespace {
 
 __device__ __forceinline__ float h2f(unsigned short h) { return __half2float(__ushort_as_half(h)); }
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// clamp to [0, hi], hi >= 0 and wave-uniform (a texture extent - 1): the median of (v, 0, hi) in one instruction -- the compare /
+// select / min the plain expression compiles to is three, and the samplers below clamp two indices per axis and tap
+__device__ __forceinline__ int clampi(int v, int /*lo == 0*/, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "s"(hi));
+    return r;
+}
 __device__ __forceinline__ float lerpx(float p, float q, float t) { return p + t * (q - p); }
 // The same value for a COMPILE-TIME fraction: when t is a power of two, t * (q - p) is exact (texels are fp16: no fp32 underflow within
 // reach), so one FMA rounds exactly like the multiply-add pair; other fractions keep the sampler's two roundings.
@@ -120,8 +126,10 @@ __device__ __forceinline__ float2 fetch_rg16f(__amdgpu_buffer_rsrc_t rs, int w, 
 // kCentreExact (frames up to 8192^2): every tap the shader aims at a texel centre -- the 3x3 neighbourhood, depth, the
 // velocity tap and the outer Catmull-Rom taps -- is one texel fetch, and the outer taps need neither their division by the
 // texture size nor the bilinear split (their texel is floor(sp - 0.5) - 1 / + 2).  Otherwise every tap goes through the sampler.
+struct TaaParams { PbrkTaaArgs a; float psx, psy; };       // 1 / width, 1 / height: the shader's divisions (:190), done once on the host
 template <bool kCentreExact, bool kHalfOut>
-__global__ __launch_bounds__(256) void k_taa_resolve(PbrkTaaArgs A) {
+__global__ __launch_bounds__(256) void k_taa_resolve(TaaParams P) {
+    const PbrkTaaArgs& A = P.a;
     const int px = blockIdx.x * 64 + (threadIdx.x & 63);
     const int py = A.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (px >= A.width || py >= A.y1) return;
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256) void k_taa_resolve(PbrkTaaArgs A) {
     const int W = LR.width, H = LR.height;
     const __amdgpu_buffer_rsrc_t rs_lr = tex_rsrc(LR, 8), rs_hi = tex_rsrc(HI, 8), rs_v = tex_rsrc(A.gbuffer_velocity, 4), rs_pv = tex_rsrc(A.gbuffer_velocity_prev, 4);
     const float tsx = (float)W, tsy = (float)H;                                 // :189
-    const float psx = 1.0f / tsx, psy = 1.0f / tsy;                             // :190
+    const float psx = P.psx, psy = P.psy;                                       // :190 (1.0f / tsx, 1.0f / tsy: IEEE divisions, identical on the host)
     const float uvx = ((float)px + 0.5f) * psx, uvy = ((float)py + 0.5f) * psy; // :192
 
     float tot[3] = {0, 0, 0}, wsum = 0.0f, m1[3] = {0, 0, 0}, m2[3] = {0, 0, 0};
@@ -458,6 +466,74 @@ __global__ __launch_bounds__(256) void k_bloom_pass(BloomParams P) {
     *o = pack_half4(r[0], r[1], r[2]);
 }
 
+// K10 / K11, SMALL levels through the general sampler (the passes of a 1080p frame below 240 x 135, whose sizes are not 2 : 1): a level
+// of a few thousand pixels cannot fill the chip, so a pass lasts as long as ONE thread's chain of 52 / 36 dependent-address fetches
+// and ~1000 instructions.  Here four lanes share a pixel, one per group of the shader's sum (downsample: centre | four corners at
+// +-2 | four edges at +-2 | four inner taps at +-1; upsample: centre | four edges | four corners | idle): a lane runs at most four
+// taps, sums them in the shader's order, and lane 0 of the pixel folds the group sums -- again in the shader's order -- after three
+// shuffles per channel.  Same taps, same operations, same order: bit-identical; the chain is a third as long.
+template <bool kUp>
+__global__ __launch_bounds__(256) void k_bloom_small(BloomParams P) {
+    const PbrkBloomArgs& A = P.a;
+    const int q = threadIdx.x & 3;
+    const int px = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int py = A.y0 + blockIdx.y;
+    const bool live = px < A.dst_width;                                                 // whole quads of lanes: the shuffles below stay inside a pixel
+    const int pxc = min(px, A.dst_width - 1);
+    const int SW = A.src.width, SH = A.src.height;
+    const __amdgpu_buffer_rsrc_t rs = tex_rsrc(A.src, 8);
+    SharedRcp rw, rh;
+    rw.d = (float)A.dst_width; rw.r = P.rcp_dw; rh.d = (float)A.dst_height; rh.r = P.rcp_dh;
+    const float u = div_by((float)pxc + 0.5f, rw), v = div_by((float)py + 0.5f, rh);      // fs_uv, as in bloom_general
+    const bool centre = q == 0 || (kUp && q == 3);
+    const bool edge = kUp ? q == 1 : q == 2;
+    const float mag = centre ? 0.0f : (kUp || q == 3) ? 1.0f : 2.0f;                     // tap offsets in units of x_step / y_step
+    float g[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // corners (and the inner taps): (-,-) (+,-) (-,+) (+,+);  edges: (0,-) (-,0) (+,0) (0,+);  centre: (0,0)
+        const float cx = (j & 1) ? 1.0f : -1.0f, cy = (j & 2) ? 1.0f : -1.0f;
+        const float ex = j == 1 ? -1.0f : j == 2 ? 1.0f : 0.0f, ey = j == 0 ? -1.0f : j == 3 ? 1.0f : 0.0f;
+        const float offx = (edge ? ex : cx) * mag, offy = (edge ? ey : cy) * mag;        // exact: +-2, +-1 or 0 (a centre lane repeats its tap)
+        int i0, i1, j0, j1; float a, b;
+        split_axis(u + offx * P.x_step, SW, i0, i1, a);
+        split_axis(v + offy * P.y_step, SH, j0, j1, b);
+        Rgba t00 = fetch_rgba16f(rs, SW, i0, j0), t10 = fetch_rgba16f(rs, SW, i1, j0);
+        Rgba t01 = fetch_rgba16f(rs, SW, i0, j1), t11 = fetch_rgba16f(rs, SW, i1, j1);
+        const float t[3] = {lerpx(lerpx(t00.x, t10.x, a), lerpx(t01.x, t11.x, a), b), lerpx(lerpx(t00.y, t10.y, a), lerpx(t01.y, t11.y, a), b),
+                            lerpx(lerpx(t00.z, t10.z, a), lerpx(t01.z, t11.z, a), b)};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[c] = j == 0 ? t[c] : (centre ? g[c] : g[c] + t[c]);   // ((t0 + t1) + t2) + t3; the centre group is its one tap
+    }
+    const int base = (threadIdx.x & 63) & ~3;
+    float r[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float g1 = __shfl(g[c], base + 1), g2 = __shfl(g[c], base + 2), g3 = __shfl(g[c], base + 3);
+        if (kUp) {                                                                      // bloom_upsample.glsl:43-58
+            const float factor = A.dst_mip_level == 0 ? 0.06f : 1.0f;
+            float sum = g[c] * 4.0f;
+            sum = sum + g1 * 2.0f;
+            sum = sum + g2;
+            r[c] = sum * factor / 16.0f;
+        } else {                                                                        // bloom_downsample.glsl:50-97
+            float sum = g[c] * 0.125f;
+            sum = sum + g1 * 0.03125f;
+            sum = sum + g2 * 0.0625f;
+            sum = sum + g3 * 0.125f;
+            if (A.dst_mip_level == 1) sum = fminf(sum, 1.0f);
+            r[c] = sum;
+        }
+    }
+    if (!live || q != 0) return;
+    uint2* o = (uint2*)A.dst + (size_t)py * A.dst_width + px;
+    if (A.blend_additive) {
+        Rgba d = unpack_rgba16f(*o);
+        r[0] = r[0] + d.x; r[1] = r[1] + d.y; r[2] = r[2] + d.z;
+    }
+    *o = pack_half4(r[0], r[1], r[2]);
+}
+
 // N consecutive texels (rgb) of row y starting at column x0: whole-row loads when the run lies inside the level, else texel by texel
 // with the sampler's clamp to edge (a tap whose two texels clamp to the same one returns it whatever its fraction: p + t (p - p)).
 template <int N>
@@ -619,10 +695,11 @@ extern "C" int pbrk_taa_resolve(const PbrkTaaArgs* a, void* stream) {
     const bool half = a->out_format == PBRK_FMT_RGBA16F;
     dim3 grid((a->width + 63) / 64, (a->y1 - a->y0 + 3) / 4), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (centre && half) hipLaunchKernelGGL((k_taa_resolve<true, true>), grid, block, 0, st, *a);
-    else if (centre) hipLaunchKernelGGL((k_taa_resolve<true, false>), grid, block, 0, st, *a);
-    else if (half) hipLaunchKernelGGL((k_taa_resolve<false, true>), grid, block, 0, st, *a);
-    else hipLaunchKernelGGL((k_taa_resolve<false, false>), grid, block, 0, st, *a);
+    TaaParams tp; tp.a = *a; tp.psx = 1.0f / (float)a->lighting_result.width; tp.psy = 1.0f / (float)a->lighting_result.height;
+    if (centre && half) hipLaunchKernelGGL((k_taa_resolve<true, true>), grid, block, 0, st, tp);
+    else if (centre) hipLaunchKernelGGL((k_taa_resolve<true, false>), grid, block, 0, st, tp);
+    else if (half) hipLaunchKernelGGL((k_taa_resolve<false, true>), grid, block, 0, st, tp);
+    else hipLaunchKernelGGL((k_taa_resolve<false, false>), grid, block, 0, st, tp);
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
 
@@ -668,6 +745,15 @@ extern "C" int pbrk_bloom_pass(const PbrkBloomArgs* a, void* stream) {
         dim3 qgrid((a->dst_width / 2 + 63) / 64, ((a->y1 - a->y0) / 2 + 3) / 4);
         if (a->upsample) hipLaunchKernelGGL((k_bloom_quad<true>), qgrid, dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((k_bloom_quad<false>), qgrid, dim3(256), 0, (hipStream_t)stream, p);
+        return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+    }
+    // four lanes per pixel where a level is too small to fill the chip and goes through the general sampler (PBR_BLOOM_SMALL_MAX_PIXELS)
+    static long long small_max = -1;
+    if (small_max < 0) { const char* e = getenv("PBR_BLOOM_SMALL_MAX_PIXELS"); small_max = e ? atoll(e) : 40000; }
+    if (!p.exact2to1 && (long long)a->dst_width * (a->y1 - a->y0) <= small_max) {
+        dim3 sgrid((a->dst_width + 63) / 64, a->y1 - a->y0);
+        if (a->upsample) hipLaunchKernelGGL((k_bloom_small<true>), sgrid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((k_bloom_small<false>), sgrid, dim3(256), 0, (hipStream_t)stream, p);
         return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
     }
     dim3 grid((a->dst_width + 63) / 64, (a->y1 - a->y0 + 3) / 4), block(256);
