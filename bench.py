@@ -912,7 +912,9 @@ def post_bench(L, pbrhip, frames=20):
            "mpixels_per_s_wall": W * H * frames / wall_untimed / 1e6, "us_per_frame_wall": wall_untimed / frames * 1e6,
            "us_per_frame_wall_with_op_events": wall / frames * 1e6,
            "us_per_frame_kernels": float(sum(sum(v) for v in ms.values()) / frames * 1e3),
-           "note": "bloom entries: mean over the 6 passes of a frame (avg_ms and alg_bytes per pass)", "kernels": []}
+           "note": "bloom entries: mean over the 6 passes of a frame (avg_ms and alg_bytes per pass); us_per_frame_kernels is the sum of the per-op HIP-event "
+                   "timings of the frame's ~21 ops (each pair of events adds ~2.5 us of stream time to its op): rocprofv3's kernel trace of the same "
+                   "frames without events is profiles/r03_post_kernel_trace.txt (tools/post_prof.sh)", "kernels": []}
     # bloom bytes: every pass reads its source level once and writes (upsample: reads + writes) its target, 8 B per texel
     lv = lambda w, h, m: max(1, w >> m) * max(1, h >> m)
     down_b = sum(8.0 * ((W * H if m == 0 else lv(W // 2, H // 2, m - 1)) + lv(W // 2, H // 2, m)) for m in range(6)) / 6
