@@ -83,6 +83,9 @@ int pbrk_box_downsample(const void* src, int ns, void* dst, int nlayers, void* s
 /* linear blit between whole RGBA32F subresources of any two sizes (all `nlayers` layers): the resample an odd mip level and a
  * non-2:1 GPU_OpBlit need (vkCmdBlitImage, unnormalised linear filter, clamp to edge; rule stated in oracle/pbr_oracle.c A2) */
 int pbrk_blit_linear(const void* src, int ns_w, int ns_h, void* dst, int nd_w, int nd_h, int nlayers, void* stream);
+/* GPU_OpClearColorF / GPU_OpClearColorI [gpu.h]: `bytes` at dst filled with a texel pattern of 1, 2, 4, 8 or 16 bytes (dst and bytes
+ * multiples of the pattern size), one launch. */
+int pbrk_fill_pattern(void* dst, unsigned long long bytes, const void* pattern, int pattern_bytes, void* stream);
 
 /* ---- border build: pyramid -> bordered pyramid (seamless-cube apron; sampler state of
  *      src/gpu/gpu_vulkan.c:613-634 applied to a cube view). */

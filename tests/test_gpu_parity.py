@@ -528,6 +528,40 @@ def test_shade_tile_kernel_equals_fast_kernel_and_oracle(gpu, size, mode):
     gpu.PBR_DestroyIBLMaps(C.byref(maps)); gpu.GPU_DestroyTexture(env_tex)
 
 
+def test_fill_pattern_every_size_and_alignment(gpu):
+    """pbrk_fill_pattern (the clear of GPU_OpClearColorF / I): every pattern size, destinations that start 0 .. 15 bytes past a 16-byte
+    boundary, lengths with and without a sub-16-byte head and tail, guard bytes on both sides untouched; and through the API: an
+    all-levels clear of a texture whose byte count is not a multiple of 16 (the 1080p bloom target's case) to a non-zero value."""
+    import pbrhip
+    rng = np.random.default_rng(0x5EED00C1)
+    N = 1 << 16
+    hb = gpu.GPU_MakeBuffer(N, pbrhip.BufferFlag_CPU, None)                     # pinned host memory the device can write
+    host = np.frombuffer((C.c_uint8 * N).from_address(hb.contents.data), dtype=np.uint8)
+    dptr = gpu.GPUX_BufferDevicePtr(hb)
+    for pb in (1, 2, 4, 8, 16):
+        pat = rng.integers(1, 255, pb, dtype=np.uint8)
+        cpat = (C.c_uint8 * pb)(*pat.tolist())
+        for start in range(0, 32, pb):
+            for nbytes in (0, pb, 16, 48, 4096 + pb, 40000 // pb * pb + pb):
+                host[:] = 0xEE
+                assert gpu.pbrk_fill_pattern(dptr + 64 + start, nbytes, cpat, pb, None) == 0
+                gpu.GPU_WaitUntilIdle()
+                want = np.full(N, 0xEE, np.uint8)
+                want[64 + start:64 + start + nbytes] = np.tile(pat, nbytes // pb)
+                assert np.array_equal(host, want), (pb, start, nbytes)
+    assert gpu.pbrk_fill_pattern(dptr + 1, 8, (C.c_uint8 * 4)(1, 2, 3, 4), 4, None) != 0                # misaligned for its pattern
+    assert gpu.pbrk_fill_pattern(dptr, 6, (C.c_uint8 * 4)(1, 2, 3, 4), 4, None) != 0                    # not a whole number of patterns
+    gpu.GPU_DestroyBuffer(hb)
+    t = gpu.GPU_MakeTexture(pbrhip.Format_RGBA32F, 30, 17, 1, pbrhip.TextureFlag_HasMipmaps | pbrhip.TextureFlag_RenderTarget, None)
+    g = gpu.GPU_MakeGraph()
+    gpu.GPU_OpClearColorF(g, t, 0xFFFFFFFF, 1.5, -2.0, 3.25, 4.0)                 # GPU_MIP_LEVEL_ALL
+    gpu.GPU_GraphSubmit(g); gpu.GPU_GraphWait(g)
+    for m in range(t.contents.mip_level_count):
+        lv = pbrhip.read_mip(t, m)
+        assert np.array_equal(lv.reshape(-1, 4), np.tile(np.float32([1.5, -2.0, 3.25, 4.0]), (lv.size // 4, 1))), m
+    gpu.GPU_DestroyGraph(g); gpu.GPU_DestroyTexture(t)
+
+
 def test_cube_sampler_convention_switch(gpu, env64):
     """the reference leaves the cube sampler's arithmetic to the driver (gpu_vulkan.c:613-634); this repo's default is
     exact fp32 tap weights, real texture units resolve 8 sub-texel / LOD-fraction bits.  pbrk_set_cube_sampler_snap(1) /

@@ -1545,11 +1545,11 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
                 bool zero = op.clear[0] == 0 && op.clear[1] == 0 && op.clear[2] == 0 && op.clear[3] == 0;
                 if (!zero) { gpu_fail("GPU_OpClearColorF: non-zero clears of format %d are not implemented", (int)t->base.format); return; }
             }
-            bool all_same = true;
-            for (uint32_t k = 1; k < tb; ++k) all_same &= texel[k] == texel[0];
-            if (all_same) { HIP_OK(hipMemsetAsync(p, texel[0], bytes, st)); }
-            else if (tb == 4) { uint32_t v; memcpy(&v, texel.data(), 4); HIP_OK(hipMemsetD32Async((hipDeviceptr_t)p, (int)v, bytes / 4, st)); }
-            else {
+            // one fill launch for every texel size and alignment (k_cube.hip)
+            if (tb == 1 || tb == 2 || tb == 4 || tb == 8 || tb == 16) {
+                int rc = pbrk_fill_pattern(p, bytes, texel.data(), (int)tb, st);
+                if (rc != PBRK_OK) gpu_fail("clear launch failed (%d)", rc);
+            } else {
                 std::vector<uint8_t> host(bytes);
                 for (size_t o = 0; o < bytes; o += tb) memcpy(host.data() + o, texel.data(), tb);
                 HIP_OK(hipMemcpyAsync(p, host.data(), bytes, hipMemcpyHostToDevice, st));
@@ -1593,11 +1593,8 @@ static bool op_replayable(const Op& op) {
     case Op_Blit: return true;
     case Op_CopyB2B: case Op_CopyB2T: case Op_CopyT2B: return false;          // host pointers may be involved: keep them out of captures
     case Op_Clear: {
-        const TextureImpl* t = op.tex;
-        // only the memset forms (the staged form synchronises)
-        if (t->texel_bytes == 4) return true;
-        if (op.clear_mode != 0) return false;
-        return op.clear[0] == 0 && op.clear[1] == 0 && op.clear[2] == 0 && op.clear[3] == 0;
+        const uint32_t tb = op.tex->texel_bytes;                              // one fill launch; the staged form of other texel sizes synchronises
+        return tb == 1 || tb == 2 || tb == 4 || tb == 8 || tb == 16;
     }
     case Op_Shade: {
         KernelId k = op.gpipe->kernel;

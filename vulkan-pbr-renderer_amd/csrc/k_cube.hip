@@ -256,6 +256,36 @@ extern "C" int pbrk_blit_linear(const void* src, int ns_w, int ns_h, void* dst, 
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
 
+// GPU_OpClearColor* (gpu.h: clear one level or all of them): `bytes` of device memory filled with a texel pattern of 1, 2, 4, 8 or 16
+// bytes, one launch whatever the alignment and size.  (hipMemsetAsync splits an all-levels clear of the 1080p bloom target -- 22 MB
+// that are not a multiple of 16 -- into a bulk and a 256-thread remainder kernel of 6.4 + 4.9 us, and has no 8- / 16-byte form.)
+__global__ __launch_bounds__(256) void k_fill_pattern(unsigned char* __restrict__ p, size_t bytes, uint4 pat) {
+    size_t head = (16 - ((size_t)p & 15)) & 15;                   // bytes up to the first 16-byte boundary: a multiple of the pattern size
+    if (head > bytes) head = bytes;
+    const size_t body = (bytes - head) >> 4, tail = bytes - head - (body << 4);
+    uint4* v = (uint4*)(p + head);
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = i0; i < body; i += stride) v[i] = pat;
+    const unsigned char* pb = (const unsigned char*)&pat;
+    if (i0 < head) p[i0] = pb[i0];                                 // the pattern starts at p: byte k holds pattern byte k mod size = byte k of its 16-byte repeat
+    if (i0 < tail) p[head + (body << 4) + i0] = pb[i0];
+}
+
+extern "C" int pbrk_fill_pattern(void* dst, unsigned long long bytes, const void* pattern, int pattern_bytes, void* stream) {
+    if (!dst || !pattern || (pattern_bytes != 1 && pattern_bytes != 2 && pattern_bytes != 4 && pattern_bytes != 8 && pattern_bytes != 16)) return PBRK_E_ARG;
+    if (bytes % (unsigned long long)pattern_bytes || ((size_t)dst % (size_t)pattern_bytes)) return PBRK_E_ARG;
+    if (!bytes) return PBRK_OK;
+    unsigned char rep[16];
+    for (int k = 0; k < 16; ++k) rep[k] = ((const unsigned char*)pattern)[k % pattern_bytes];
+    uint4 pat;
+    __builtin_memcpy(&pat, rep, 16);
+    const unsigned long long vecs = bytes / 16 + 1;
+    unsigned blocks = (unsigned)((vecs + 1023) / 1024);           // four 16-byte stores per thread on a big fill
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_fill_pattern, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char*)dst, (size_t)bytes, pat);
+    return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+}
+
 // Level sizes are the reference's (gpu_vulkan.c:1344-1351, 1458-1483): n_l = max(1, W >> l), as many levels as 1 + floor(log2 W).
 // A level that is exactly half its source takes the 2x2 box kernels (two levels per launch while that holds for both); an odd
 // source (faces that are not a power of two) takes the linear resample.
