@@ -224,6 +224,10 @@ typedef struct PbrkBloomArgs {
     int y0, y1;
 } PbrkBloomArgs;
 int pbrk_bloom_pass(const PbrkBloomArgs* args, void* stream);
+/* The three instantiations of a bloom pass give the same bits: one pixel per thread; 2 x 2 pixels per thread (exact 2 : 1 passes with even
+ * sizes and at least quad_min_pixels target pixels; default 100000, env PBR_BLOOM_QUAD_MIN_PIXELS); four lanes per pixel (general-sampler
+ * passes of at most small_max_pixels target pixels; default 40000, env PBR_BLOOM_SMALL_MAX_PIXELS).  Negative = default. */
+void pbrk_bloom_set_thresholds(long long quad_min_pixels, long long small_max_pixels);
 
 /* ---- diagnostics: the device samplers of the widened passes evaluated at caller-supplied coordinates, so that tests can feed them
  *      NaN / inf / 1e30 / boundary values directly (a ray that has marched far away must never become an out-of-bounds read).

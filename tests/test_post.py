@@ -323,6 +323,35 @@ def test_gpu_post_wide_frames(gpu, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("size", [(64, 32), (96, 64), (256, 144), (130, 68), (520, 264)])
+def test_gpu_bloom_instantiations_agree_on_small_and_ragged_frames(gpu, size):
+    """The bloom chain's three instantiations (one pixel per thread | 2 x 2 pixels per thread on exact 2 : 1 passes | four lanes per pixel
+    through the general sampler) forced onto frames where nearly every block touches an edge: each forced choice gives the oracle's bits
+    on every level, for sizes whose chains mix even, odd and 2 : 1 / non-2 : 1 levels."""
+    import pbrhip
+    from pbrhip.synth import synth_post_inputs
+    L = gpu
+    W, H = size
+    taa, _, _, _, _ = synth_post_inputs(0x5EED00DB, W, H)
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), W, H, pbrhip.Format_RGBA16F)
+    pp = L.PBR_MakePostProcess(C.byref(gb), W, H, pbrhip.Format_BGRA8UN)
+    _upload(L.PBR_PostTaaOutput(pp, 0), taa)
+    n = L.PBR_PostBloomPassCount(pp)
+    want_down, want_up = O.bloom_chain(taa, n)
+    try:
+        for quad_min, small_max in ((1 << 40, 0), (0, 0), (1 << 40, 1 << 40), (0, 1 << 40)):
+            L.pbrk_bloom_set_thresholds(quad_min, small_max)
+            g = L.GPU_MakeGraph()
+            L.PBR_RecordBloom(pp, g, 0)
+            L.GPU_GraphSubmit(g); L.GPU_GraphWait(g); L.GPU_DestroyGraph(g)
+            _check_bloom(L, pbrhip, pp, want_down, want_up)
+    finally:
+        L.pbrk_bloom_set_thresholds(-1, -1)
+    L.PBR_DestroyPostProcess(pp); L.PBR_DestroyGBuffer(C.byref(gb))
+
+
+@pytest.mark.gpu
 def test_gpu_frame_chain_hipgraph_replay_is_identical(gpu):
     """GPUX_SetGraphReplay: the per-frame chain (light-grid sweep, shade, TAA resolve, bloom, tone map; two graphs in flight as in
     main.cpp:49-51, 91-99, camera and ping-pong targets changing every frame) submitted through a captured / updated hipGraph

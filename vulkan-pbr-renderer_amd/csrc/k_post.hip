@@ -724,6 +724,10 @@ extern "C" int pbrk_final_post_process(const PbrkFinalArgs* a, void* stream) {
     return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
 }
 
+// which instantiation a bloom pass takes (all bit-identical): < 0 = the environment variable or the default
+static long long g_quad_min = -1, g_small_max = -1;
+extern "C" void pbrk_bloom_set_thresholds(long long quad_min_pixels, long long small_max_pixels) { g_quad_min = quad_min_pixels; g_small_max = small_max_pixels; }
+
 extern "C" int pbrk_bloom_pass(const PbrkBloomArgs* a, void* stream) {
     if (!a || !a->dst || a->dst_width < 1 || a->dst_height < 1 || a->y0 < 0 || a->y0 >= a->y1 || a->y1 > a->dst_height) return PBRK_E_ARG;
     if (!tex_ok(a->src, PBRK_FMT_RGBA16F)) return PBRK_E_FORMAT;
@@ -738,8 +742,8 @@ extern "C" int pbrk_bloom_pass(const PbrkBloomArgs* a, void* stream) {
     p.exact2to1 = small && (a->upsample ? (a->dst_width == 2 * a->src.width && a->dst_height == 2 * a->src.height)
                                         : (a->src.width == 2 * a->dst_width && a->src.height == 2 * a->dst_height));
     // 2 x 2 pixels per thread where the level is large enough to fill the chip with such threads (PBR_BLOOM_QUAD_MIN_PIXELS)
-    static long long quad_min = -1;
-    if (quad_min < 0) { const char* e = getenv("PBR_BLOOM_QUAD_MIN_PIXELS"); quad_min = e ? atoll(e) : 100000; }
+    if (g_quad_min < 0) { const char* e = getenv("PBR_BLOOM_QUAD_MIN_PIXELS"); g_quad_min = e ? atoll(e) : 100000; }
+    const long long quad_min = g_quad_min;
     const bool even = !((a->dst_width | a->dst_height | a->y0 | a->y1) & 1) && ((uintptr_t)a->dst & 15) == 0 && ((uintptr_t)a->src.data & 15) == 0;
     if (p.exact2to1 && even && (long long)a->dst_width * (a->y1 - a->y0) >= quad_min) {
         dim3 qgrid((a->dst_width / 2 + 63) / 64, ((a->y1 - a->y0) / 2 + 3) / 4);
@@ -748,8 +752,8 @@ extern "C" int pbrk_bloom_pass(const PbrkBloomArgs* a, void* stream) {
         return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
     }
     // four lanes per pixel where a level is too small to fill the chip and goes through the general sampler (PBR_BLOOM_SMALL_MAX_PIXELS)
-    static long long small_max = -1;
-    if (small_max < 0) { const char* e = getenv("PBR_BLOOM_SMALL_MAX_PIXELS"); small_max = e ? atoll(e) : 40000; }
+    if (g_small_max < 0) { const char* e = getenv("PBR_BLOOM_SMALL_MAX_PIXELS"); g_small_max = e ? atoll(e) : 40000; }
+    const long long small_max = g_small_max;
     if (!p.exact2to1 && (long long)a->dst_width * (a->y1 - a->y0) <= small_max) {
         dim3 sgrid((a->dst_width + 63) / 64, a->y1 - a->y0);
         if (a->upsample) hipLaunchKernelGGL((k_bloom_small<true>), sgrid, dim3(256), 0, (hipStream_t)stream, p);

@@ -224,6 +224,7 @@ PROTOTYPES = {
     "pbrk_set_cube_sampler_snap": (None, [C.c_int]), "pbrk_get_cube_sampler_snap": (C.c_int, []), "pbrk_box_downsample": (C.c_int, [VP, C.c_int, VP, C.c_int, VP]),
     "pbrk_blit_linear": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_int, VP]),
     "pbrk_fill_pattern": (C.c_int, [VP, C.c_ulonglong, VP, C.c_int, VP]),
+    "pbrk_bloom_set_thresholds": (None, [C.c_longlong, C.c_longlong]),
     "pbrk_border_build": (C.c_int, [VP, VP, C.c_int, C.c_int, VP]),
     "pbrk_border_build_range": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "pbrk_debug_sample": (C.c_int, [C.c_int, VP, C.c_int, C.c_int, C.c_int, VP, C.c_int, VP, VP]),
