@@ -186,7 +186,8 @@ static double samples_per_texel(uint32_t mip) {
     return 8192.0;
 }
 
-/* Measured time per sample-evaluation relative to mip 2 (one MI355X, C4, round 2 kernels: the region kernel serves mips 1-3,
+/* Measured time per sample-evaluation relative to mip 2 (one MI355X, C4, round 3 kernels; the values for mips >= 4 and the copy level are
+ * fitted to the shares of an 8-way split, tools/rank_time.py, where those levels run as partial dispatches with short tails: the region kernel serves mips 1-3,
  * the level-in-LDS kernel mips >= 4; bench.py per-level times divided by 6 * size^2 * non-zero samples): mip 1 runs quarter-face
  * regions (more passes per tile), mip 3 has 33-cell faces (more samples on two faces), the small levels are launch / tail
  * limited.  The copy mip writes 16 B per texel at ~3.3 TB/s, i.e. as long as ~5.8 sample-evaluations per texel.
@@ -194,13 +195,13 @@ static double samples_per_texel(uint32_t mip) {
 static double time_weight(const PBR_WorkUnit* u) {
     if (u->kind == PBR_Unit_Irradiance) return 1.24;
     switch (u->mip) {
-    case 0: return 5.8;
-    case 1: return 1.24;
+    case 0: return 4.5;
+    case 1: return 1.19;
     case 2: return 1.0;
-    case 3: return 1.18;
-    case 4: return 1.5;
-    case 5: return 1.34;
-    default: return 1.34;
+    case 3: return 1.14;
+    case 4: return 2.0;
+    case 5: return 1.5;
+    default: return 1.5;
     }
 }
 
