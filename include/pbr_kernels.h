@@ -130,6 +130,9 @@ int pbrk_mc_filter(const void* src_bordered_level, const void* src_cells, int n_
 /* self-check of the region kernel (PBR_MC_STATS=1): {wave-slices whose sample count came up short and were recomputed with
  * direct loads, all wave-slices}; the first must stay 0.  reset != 0 clears the counters after reading. */
 int pbrk_mc_region_stats(unsigned long long* out2, int reset);
+/* K4b / K3 kernel choice for tests and A-B runs: region = 0 skips the region kernel, lds = 0 the level-in-LDS kernel (the direct kernel
+ * then serves every level); -1 = the environment (PBR_MC_REGION, PBR_MC_LDS) or the default 1.  Results agree to the order of the fp32 sums. */
+void pbrk_mc_set_kernels(int region, int lds);
 /* the binning's yield with the same switch: {(region, sample) flags set, samples x tiles, regions visited} summed over all tiles since the last reset */
 int pbrk_mc_region_flag_stats(unsigned long long* out3);
 /* samples that binning proved to tap one region from every texel of their tile (they run the body without tests), summed over tiles */
@@ -177,6 +180,7 @@ int pbrk_shade(const PbrkShadeArgs* args, void* stream);
  * on the host in the shader's operation order); pbrk_shade_tables_ready: they exist (the first launch of a frame size builds
  * them with a synchronous upload, so that launch cannot be part of a stream capture: pbrk_shade_needs_tables). */
 void pbrk_shade_set_tile_min_pixels(long long pixels);
+void pbrk_shade_set_fast(int on);                        /* 0: every mode through the general kernel k_shade (env PBR_SHADE_FAST); -1 = default */
 int pbrk_shade_tables_ready(int width, int height);
 int pbrk_shade_needs_tables(int width, int height);     /* the next launch of this frame size would build them (not capturable) */
 /* LUT twin for K5: one 16-byte load per bilinear LUT fetch */

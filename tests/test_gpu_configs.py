@@ -154,6 +154,25 @@ def _shade_full_size(L, gbd, bands, oracle_rows, expect_sky, expect_overflow=Fal
     del banded
     f32 = full.view(np.float16)
     assert not np.isnan(f32).any() and (f32[..., 3] == 1).all() and (f32[..., :3] >= 0).all()
+    # EVERY pixel: the fast instantiation (k_shade_fast: buffer loads from the cells twins, shared-reciprocal chain) against the general
+    # kernel (k_shade: the shader statement by statement) on the whole frame -- two implementations of the same draw, each within 1e-4
+    # of the oracle on its rows, so within 2e-4 of each other wherever they are compared
+    L.PBR_RecordLightingPass(lp32, g, C.byref(glob), 0, 0)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    fast32 = pbrhip.read_mip(gb32.lighting_result, 0)[..., :3].copy()
+    try:
+        L.pbrk_shade_set_fast(0)
+        L.PBR_RecordLightingPass(lp32, g, C.byref(glob), 0, 0)
+        L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
+    finally:
+        L.pbrk_shade_set_fast(-1)
+    gen32 = pbrhip.read_mip(gb32.lighting_result, 0)[..., :3]
+    worst = 0.0
+    for y0 in range(0, H, 270):                                     # in slabs: the float64 temporaries of an 8K frame would be 2.4 GB
+        a, b = fast32[y0:y0 + 270].astype(np.float64), gen32[y0:y0 + 270].astype(np.float64)
+        worst = max(worst, float((np.abs(a - b) / np.maximum(np.abs(b), 1e-2)).max()))
+    assert worst < 2 * REL, worst
+    del fast32, gen32
     for y in oracle_rows:
         L.PBR_RecordLightingPass(lp32, g, C.byref(glob), y, y + 1)
     L.GPU_GraphSubmit(g); L.GPU_GraphWait(g)
@@ -182,6 +201,37 @@ def _shade_full_size(L, gbd, bands, oracle_rows, expect_sky, expect_overflow=Fal
     L.GPU_DestroyGraph(g); L.PBR_DestroyLightingPass(lp); L.PBR_DestroyLightingPass(lp32)
     L.GPU_DestroyTexture(gb32.lighting_result); L.PBR_DestroyGBuffer(C.byref(gb))
     L.PBR_DestroyIBLMaps(C.byref(maps)); L.GPU_DestroyTexture(env_tex)
+
+
+def test_c4_every_texel_region_kernel_against_direct_kernel(gpu, c4_env):
+    """C4 at full size, EVERY texel of the Monte-Carlo levels 1-5 (33.5 M texels; the oracle covers three rows per level): the
+    shipped kernels (LDS-staged regions for mips 1-4, level-in-LDS below) against the round-1 direct kernel -- different code
+    for face selection, tap addressing and staging, the same taps and weights -- agree to the order of their fp32 sums."""
+    import pbrhip
+    L = gpu
+    W, S = 2048, 4096
+    tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, W, W, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, c4_env)
+    spec = pbrhip.make_texture(pbrhip.Format_RGBA32F, S, S, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps | pbrhip.TextureFlag_StorageImage)
+    try:
+        L.pbrk_mc_set_kernels(1, 1)
+        L.PBR_GenPrefilteredEnvMap(tex, spec, 128)
+        shipped = [pbrhip.read_mip(spec, m) for m in range(1, 6)]
+        g = L.GPU_MakeGraph()
+        for m in range(1, 6):
+            L.GPU_OpClearColorF(g, spec, m, 0.0, 0.0, 0.0, 0.0)
+        L.GPU_GraphSubmit(g); L.GPU_GraphWait(g); L.GPU_DestroyGraph(g)
+        L.pbrk_mc_set_kernels(0, 0)
+        L.PBR_GenPrefilteredEnvMap(tex, spec, 128)
+        for m in range(1, 6):
+            a = shipped[m - 1]
+            b = pbrhip.read_mip(spec, m)
+            assert float(np.abs(a[..., :3]).max()) > 0 and np.array_equal(a[..., 3], b[..., 3])
+            err = np.abs(a[..., :3].astype(np.float64) - b[..., :3]) / np.maximum(np.abs(a[..., :3]), 1e-3)
+            assert float(err.max()) < 2e-5, (m, float(err.max()))
+            shipped[m - 1] = None
+    finally:
+        L.pbrk_mc_set_kernels(-1, -1)
+    L.GPU_DestroyTexture(spec); L.GPU_DestroyTexture(tex)
 
 
 def test_c3_shade_spheres_oracle_rows(gpu):

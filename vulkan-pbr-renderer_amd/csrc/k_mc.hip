@@ -203,8 +203,8 @@ static void launch_mc_lds_s(McArgs a, int nfaces, size_t lds, hipStream_t st) {
 
 // returns false when the level does not fit in LDS
 static bool launch_mc_lds(McArgs a, int nfaces, hipStream_t st) {
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("PBR_MC_LDS"); mode = e ? atoi(e) : 1; }
+    if (g_mc_lds_mode < 0) { const char* e = getenv("PBR_MC_LDS"); g_mc_lds_mode = e ? atoi(e) : 1; }
+    const int mode = g_mc_lds_mode;
     int nb = a.n_src + 2;
     size_t lvl_bytes = (size_t)6 * nb * nb * 16;
     if (!mode || lvl_bytes > 112 * 1024) return false;

@@ -67,3 +67,4 @@ __device__ __forceinline__ f3 sample_bordered(__amdgpu_buffer_rsrc_t rs, f3 L, f
 // k_mc_region.hip: taps from LDS-staged regions of the source level.  Returns false when the kernel does not apply
 // (the caller then takes the direct kernel); the decision depends on the level's shape only, never on the dispatched range.
 bool launch_mc_region(McArgs a, int nfaces, hipStream_t st);
+extern int g_mc_region_mode, g_mc_lds_mode;         // pbrk_mc_set_kernels (k_mc_region.hip)

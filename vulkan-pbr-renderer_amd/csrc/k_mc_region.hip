@@ -677,10 +677,14 @@ static void launch_mfma_t(const RegArgs& q, unsigned grid, size_t lds, hipStream
     hipLaunchKernelGGL((k_mc_region_mfma<RS, SUB>), dim3(grid), dim3(1024), lds, st, q);
 }
 
+// Which kernel serves a level (tests / A-B runs; -1 = the environment variable PBR_MC_REGION / PBR_MC_LDS, else the default 1)
+int g_mc_region_mode = -1, g_mc_lds_mode = -1;
+extern "C" void pbrk_mc_set_kernels(int region, int lds) { g_mc_region_mode = region; g_mc_lds_mode = lds; }
+
 bool launch_mc_region(McArgs a, int nfaces, hipStream_t st) {
-    static int mode = -1, stats_on = -1;
-    if (mode < 0) { const char* e = getenv("PBR_MC_REGION"); mode = e ? atoi(e) : 1; }
-    if (!mode) return false;
+    static int stats_on = -1;
+    if (g_mc_region_mode < 0) { const char* e = getenv("PBR_MC_REGION"); g_mc_region_mode = e ? atoi(e) : 1; }
+    if (!g_mc_region_mode) return false;
     // shape conditions (level only): source too big for LDS as a whole, enough 16x16 tiles to fill the chip twice over
     if (a.n_src < 16 || a.size < 256 || a.n_tab < 1 || a.n_tab > 8192) return false;
     RegArgs q;

@@ -555,6 +555,8 @@ extern "C" int pbrk_shade_tables_ready(int width, int height) {
     return g_shade_tables.count({width, height}) ? 1 : 0;
 }
 static long long g_tile_min_pixels = -1;        // -1: PBR_SHADE_TILE_MIN_PIXELS or the default
+static int g_fast_mode = -1;                    // -1: PBR_SHADE_FAST or the default (1)
+extern "C" void pbrk_shade_set_fast(int on) { g_fast_mode = on; }
 extern "C" void pbrk_shade_set_tile_min_pixels(long long pixels) { g_tile_min_pixels = pixels; }
 static long long tile_min_pixels() {
     if (g_tile_min_pixels < 0) { const char* e = getenv("PBR_SHADE_TILE_MIN_PIXELS"); g_tile_min_pixels = e ? atoll(e) : (1ll << 62); }
@@ -634,8 +636,8 @@ extern "C" int pbrk_shade(const PbrkShadeArgs* a, void* stream) {
     p.sun_depth = (const float*)a->sun_depth; p.sun_w = a->sun_depth_w; p.sun_h = a->sun_depth_h;
     p.rcp_width = 1.0f / (float)a->width; p.rcp_height = 1.0f / (float)a->height;
     // fast instantiation: no sun shadows / GI, power-of-two prefiltered cube with a complete cells twin (and, IBL, the two other twins)
-    static int fast_mode = -1;
-    if (fast_mode < 0) { const char* e = getenv("PBR_SHADE_FAST"); fast_mode = e ? atoi(e) : 1; }
+    if (g_fast_mode < 0) { const char* e = getenv("PBR_SHADE_FAST"); g_fast_mode = e ? atoi(e) : 1; }
+    const int fast_mode = g_fast_mode;
     p.snap = pbrk_get_cube_sampler_snap();                          // diagnostic cube-sampler convention: general kernel only
     bool fast = fast_mode && !p.snap && !(a->flags & (PBRK_SHADE_GI | PBRK_SHADE_SHADOWS)) && p.pre_cells && p.pre_cells_first == 0 &&
                 (a->prefiltered_size & (a->prefiltered_size - 1)) == 0 && a->prefiltered_size <= 512 &&

@@ -225,6 +225,7 @@ PROTOTYPES = {
     "pbrk_blit_linear": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_int, VP]),
     "pbrk_fill_pattern": (C.c_int, [VP, C.c_ulonglong, VP, C.c_int, VP]),
     "pbrk_bloom_set_thresholds": (None, [C.c_longlong, C.c_longlong]),
+    "pbrk_mc_set_kernels": (None, [C.c_int, C.c_int]), "pbrk_shade_set_fast": (None, [C.c_int]),
     "pbrk_border_build": (C.c_int, [VP, VP, C.c_int, C.c_int, VP]),
     "pbrk_border_build_range": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "pbrk_debug_sample": (C.c_int, [C.c_int, VP, C.c_int, C.c_int, C.c_int, VP, C.c_int, VP, VP]),
