@@ -949,7 +949,7 @@ def lut_bench(L, pbrhip, runs=10):
     res = {"workload": "C1: 256x256 split-sum BRDF LUT, 4096 samples per texel, RG16F target", "runs": runs, "kernel_ms": k_ms,
            "mtexels_per_s": 65536.0 / (k_ms * 1e-3) / 1e6, "msamples_per_s": evals / (k_ms * 1e-3) / 1e6,
            # executed work per (sample, texel): the row part (6 mul + 2 FMA = 10 flop, one v_exp_f32) + 1/16 of the column part (~60 flop, 3 transcendentals)
-           "roofline": {"kernel": "K1.brdf_lut", "bound": "valu", "achieved": evals * 13.75 / (k_ms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+           "roofline": {"kernel": "K1.brdf_lut", "bound": "mfma", "pipe": "fp32 VALU", "achieved": evals * 13.75 / (k_ms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                         "frac": evals * 13.75 / (k_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
                         "shader_equivalent_tflops": evals * 60.0 / (k_ms * 1e-3) / 1e12,
                         "note": "priced by the work the kernel executes (13.75 flop + 1.2 transcendentals per sample and texel: the roughness-independent part of a "
