@@ -100,5 +100,7 @@ GPU_API void GPUX_SetTileStreams(int count);
  * every submission while per-op timing is on, runs as before.  Results are identical.  enable < 0: environment PBR_GRAPH_REPLAY, else off. ---- */
 GPU_API void GPUX_SetGraphReplay(int enable);
 GPU_API void GPUX_GraphReplayStats(GPU_Graph* graph, uint64_t* launches, uint64_t* updates, uint64_t* instantiations);
+/* 1:1 blits folded into the additive bloom draw that consumes their copy, since the library was loaded (env PBR_GRAPH_FOLD=0 keeps every blit) */
+GPU_API uint64_t GPUX_FoldedBlitCount(void);
 
 #endif

@@ -226,6 +226,7 @@ typedef struct PbrkBloomArgs {
     int upsample;                       /* 0: bloom_downsample.glsl, 1: bloom_upsample.glsl */
     int blend_additive;
     int y0, y1;
+    const void* blend_src;              /* blend_additive: the operand added to the pass's result, same layout as dst; NULL = dst itself */
 } PbrkBloomArgs;
 int pbrk_bloom_pass(const PbrkBloomArgs* args, void* stream);
 /* The three instantiations of a bloom pass give the same bits: one pixel per thread; 2 x 2 pixels per thread (exact 2 : 1 passes with even

@@ -107,6 +107,10 @@ struct Op {
     uint32_t mip = 0, mip2 = 0, layer0 = 0, layer_count = 0, layer2 = 0;
     uint64_t off_a = 0, off_b = 0, size = 0;
     float clear[4]; uint32_t cleari[4]; int clear_mode = 0;
+    // submit-time folding (fold_blits): a 1:1 blit whose copy is consumed only by an additive bloom draw onto its target is not
+    // executed; that draw takes the blend operand from the blit's source instead
+    bool folded = false;
+    TextureImpl* blend_tex = nullptr; uint32_t blend_mip = 0;
 };
 struct DrawParams { GPU_GraphicsPipeline* pipeline; GPU_DescriptorSet* set; };
 struct GPU_Graph {
@@ -1375,6 +1379,7 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
                 a.dst_width = (int)rp->desc.width; a.dst_height = (int)rp->desc.height;
                 int32_t lvl; memcpy(&lvl, op.push, 4); a.dst_mip_level = lvl;
                 a.upsample = op.gpipe->kernel == Kernel_BloomUp; a.blend_additive = op.gpipe->blend_additive;
+                a.blend_src = op.blend_tex ? (const void*)((const char*)op.blend_tex->dev + op.blend_tex->mip_offset[op.blend_mip]) : nullptr;
                 a.y0 = (int)op.row0; a.y1 = (int)op.row1;
                 timed(g, a.upsample ? "K11.bloom_upsample" : "K10.bloom_downsample", ev_used, [&] {
                     int rc = pbrk_bloom_pass(&a, st);
@@ -1483,6 +1488,7 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
         return;
     }
     case Op_Blit: {
+        if (op.folded) { op.tex2->bordered_valid = false; op.tex2->lut_cells_valid = false; return; }   // its consumer reads the source (fold_blits)
         if (op.size) {                                                         // 1:1 copy of one layer
             const void* src = (const char*)op.tex->dev + op.tex->mip_offset[op.mip] + op.size * op.layer0;
             void* dst = (char*)op.tex2->dev + op.tex2->mip_offset[op.mip2] + op.size * op.layer2;
@@ -1652,6 +1658,41 @@ GPU_API void GPUX_GraphReplayStats(GPU_Graph* g, uint64_t* launches, uint64_t* u
     if (instantiations) *instantiations = g->replay_instantiations;
 }
 
+// The reference's bloom chain copies the TAA result into level 0 of bloom_upscale_rt (a 1:1 GPU_OpBlit, render.cpp:1158-1163) and, five
+// passes later, ADDS the last upsample onto that copy (additive blending, render.cpp:1165-1176).  Nothing else reads the copy: the
+// upsample can add onto the blit's SOURCE and write the sum to the target, and the copy (33 MB of traffic, one launch per 1080p frame)
+// need not exist.  Folded only when the ops between the two provably touch neither subresource: bloom draws with other sources and
+// targets; anything else in between keeps the blit.  Same values, same additions: the target's bits do not change.
+static uint64_t g_folded_blits = 0;
+GPU_API uint64_t GPUX_FoldedBlitCount(void) { return g_folded_blits; }
+static void fold_blits(GPU_Graph* g) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("PBR_GRAPH_FOLD"); on = e ? atoi(e) : 1; }
+    for (Op& op : g->ops) { op.folded = false; op.blend_tex = nullptr; }
+    if (!on) return;
+    for (size_t i = 0; i < g->ops.size(); ++i) {
+        Op& b = g->ops[i];
+        if (b.kind != Op_Blit || !b.size || b.layer0 != 0 || b.layer2 != 0 || b.tex->base.layer_count != 1 || b.tex2->base.layer_count != 1 ||
+            b.tex->base.format != GPU_Format_RGBA16F || b.tex == b.tex2) continue;
+        for (size_t j = i + 1; j < g->ops.size(); ++j) {
+            Op& d = g->ops[j];
+            if (d.kind != Op_Shade || !(d.gpipe->kernel == Kernel_BloomDown || d.gpipe->kernel == Kernel_BloomUp)) break;
+            TextureImpl* target = (TextureImpl*)d.pass->targets[0].texture;
+            Slot* in = named_slot(d.set, "TEX0");
+            if (!in || !in->tex) break;
+            const bool reads_copy = in->tex == b.tex2 && d.mip == b.mip2, writes_src = target == b.tex && d.mip2 == b.mip;
+            if (reads_copy || writes_src) break;
+            if (target == b.tex2 && d.mip2 == b.mip2) {
+                const uint32_t H = mip_dim(target->base.height, d.mip2);
+                if (d.gpipe->kernel == Kernel_BloomUp && d.gpipe->blend_additive && d.row0 == 0 && d.row1 == H && !(in->tex == b.tex && d.mip == b.mip)) {
+                    b.folded = true; d.blend_tex = b.tex; d.blend_mip = b.mip; ++g_folded_blits;
+                }
+                break;
+            }
+        }
+    }
+}
+
 GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
     GPU_REQUIRE_V(g && !g->submitted, "GPU_GraphSubmit: graph is NULL or already submitted");
     GPU_REQUIRE_V(g->in_pass == nullptr && g->preparing == nullptr, "GPU_GraphSubmit: render pass still open");
@@ -1672,6 +1713,7 @@ GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
         HIP_OK(hipStreamWaitEvent(g->stream, prev->order_ev, 0));
     }
     G.last_submitted = g;
+    fold_blits(g);
     if (G.replay < 0) { const char* e = getenv("PBR_GRAPH_REPLAY"); G.replay = e ? (atoi(e) != 0) : 0; }
     bool capture = G.replay == 1 && !G.timing && !g->replay_broken && !g->ops.empty();
     if (capture) capture = graph_replayable(g);

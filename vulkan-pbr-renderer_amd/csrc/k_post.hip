@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void k_bloom_pass(BloomParams P) {
     if (!done) bloom_general<kUp>(P, rs, px, py, r);
     uint2* o = (uint2*)A.dst + (size_t)py * A.dst_width + px;
     if (A.blend_additive) {
-        Rgba d = unpack_rgba16f(*o);
+        Rgba d = unpack_rgba16f(A.blend_src ? ((const uint2*)A.blend_src)[(size_t)py * A.dst_width + px] : *o);
         r[0] = r[0] + d.x; r[1] = r[1] + d.y; r[2] = r[2] + d.z;
     }
     *o = pack_half4(r[0], r[1], r[2]);
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void k_bloom_small(BloomParams P) {
     if (!live || q != 0) return;
     uint2* o = (uint2*)A.dst + (size_t)py * A.dst_width + px;
     if (A.blend_additive) {
-        Rgba d = unpack_rgba16f(*o);
+        Rgba d = unpack_rgba16f(A.blend_src ? ((const uint2*)A.blend_src)[(size_t)py * A.dst_width + px] : *o);
         r[0] = r[0] + d.x; r[1] = r[1] + d.y; r[2] = r[2] + d.z;
     }
     *o = pack_half4(r[0], r[1], r[2]);
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void k_bloom_quad(BloomParams P) {
     for (int oy = 0; oy < 2; ++oy) {
         uint4* o = (uint4*)((uint2*)A.dst + (size_t)(2 * qy + oy) * A.dst_width + 2 * qx);
         if (A.blend_additive) {
-            const uint4 d = *o;
+            const uint4 d = A.blend_src ? *(const uint4*)((const uint2*)A.blend_src + (size_t)(2 * qy + oy) * A.dst_width + 2 * qx) : *o;
             const Rgba d0 = unpack_rgba16f(make_uint2(d.x, d.y)), d1 = unpack_rgba16f(make_uint2(d.z, d.w));
             r[oy][0][0] = r[oy][0][0] + d0.x; r[oy][0][1] = r[oy][0][1] + d0.y; r[oy][0][2] = r[oy][0][2] + d0.z;
             r[oy][1][0] = r[oy][1][0] + d1.x; r[oy][1][1] = r[oy][1][1] + d1.y; r[oy][1][2] = r[oy][1][2] + d1.z;
@@ -744,7 +744,7 @@ extern "C" int pbrk_bloom_pass(const PbrkBloomArgs* a, void* stream) {
     // 2 x 2 pixels per thread where the level is large enough to fill the chip with such threads (PBR_BLOOM_QUAD_MIN_PIXELS)
     if (g_quad_min < 0) { const char* e = getenv("PBR_BLOOM_QUAD_MIN_PIXELS"); g_quad_min = e ? atoll(e) : 100000; }
     const long long quad_min = g_quad_min;
-    const bool even = !((a->dst_width | a->dst_height | a->y0 | a->y1) & 1) && ((uintptr_t)a->dst & 15) == 0 && ((uintptr_t)a->src.data & 15) == 0;
+    const bool even = !((a->dst_width | a->dst_height | a->y0 | a->y1) & 1) && ((uintptr_t)a->dst & 15) == 0 && ((uintptr_t)a->src.data & 15) == 0 && ((uintptr_t)a->blend_src & 15) == 0;
     if (p.exact2to1 && even && (long long)a->dst_width * (a->y1 - a->y0) >= quad_min) {
         dim3 qgrid((a->dst_width / 2 + 63) / 64, ((a->y1 - a->y0) / 2 + 3) / 4);
         if (a->upsample) hipLaunchKernelGGL((k_bloom_quad<true>), qgrid, dim3(256), 0, (hipStream_t)stream, p);
