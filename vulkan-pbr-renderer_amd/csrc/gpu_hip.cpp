@@ -111,6 +111,7 @@ struct Op {
     // executed; that draw takes the blend operand from the blit's source instead
     bool folded = false;
     TextureImpl* blend_tex = nullptr; uint32_t blend_mip = 0;
+    bool skip_level0 = false;                      // Op_Clear of all levels whose level 0 the next op overwrites entirely
 };
 struct DrawParams { GPU_GraphicsPipeline* pipeline; GPU_DescriptorSet* set; };
 struct GPU_Graph {
@@ -1537,6 +1538,7 @@ static void exec_op(GPU_Graph* g, Op& op, size_t& ev_used) {
         for (uint32_t m = m0; m < (whole ? m0 + 1 : m1); ++m) {
             size_t bytes = whole ? t->bytes : (size_t)GPUX_TextureMipBytes(&t->base, m);
             void* p = (char*)t->dev + t->mip_offset[m];
+            if (whole && op.skip_level0) { p = (char*)t->dev + t->mip_offset[1]; bytes = t->bytes - t->mip_offset[1]; }   // fold_blits
             // build one texel pattern on the host and replicate it (clears are rare: upload a staging row)
             uint32_t tb = t->texel_bytes;
             std::vector<uint8_t> texel(tb, 0);
@@ -1668,10 +1670,16 @@ GPU_API uint64_t GPUX_FoldedBlitCount(void) { return g_folded_blits; }
 static void fold_blits(GPU_Graph* g) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("PBR_GRAPH_FOLD"); on = e ? atoi(e) : 1; }
-    for (Op& op : g->ops) { op.folded = false; op.blend_tex = nullptr; }
+    for (Op& op : g->ops) { op.folded = false; op.blend_tex = nullptr; op.skip_level0 = false; }
     if (!on) return;
     for (size_t i = 0; i < g->ops.size(); ++i) {
         Op& b = g->ops[i];
+        // a clear of ALL levels directly followed by a whole-level copy onto level 0 (render.cpp:1156-1163): level 0 -- three quarters of
+        // the bytes -- is overwritten before anything can read the zeros
+        if (b.kind == Op_Blit && b.size && i > 0 && b.mip2 == 0 && b.tex2->base.layer_count == 1 && b.tex2->base.mip_level_count > 1) {
+            Op& c = g->ops[i - 1];
+            if (c.kind == Op_Clear && c.tex == b.tex2 && c.mip == GPU_MIP_LEVEL_ALL && b.tex != b.tex2) c.skip_level0 = true;
+        }
         if (b.kind != Op_Blit || !b.size || b.layer0 != 0 || b.layer2 != 0 || b.tex->base.layer_count != 1 || b.tex2->base.layer_count != 1 ||
             b.tex->base.format != GPU_Format_RGBA16F || b.tex == b.tex2) continue;
         for (size_t j = i + 1; j < g->ops.size(); ++j) {
