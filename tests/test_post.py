@@ -355,6 +355,58 @@ def test_gpu_bloom_instantiations_agree_on_small_and_ragged_frames(gpu, size):
 
 
 @pytest.mark.gpu
+def test_gpu_graph_folds_keep_a_blit_and_a_clear_that_something_else_can_see(gpu):
+    """The submit-time folds (gpu_hip.cpp fold_blits) apply to the bloom chain's own pattern only.  Here the same clear + 1:1 blit are
+    followed by a read-back of the copy instead of the bloom draws: the blit must run (the buffer holds the source's texels), and the
+    clear -- all levels, directly in front of a whole-level copy onto level 0 -- may skip level 0 only: the other levels read zero
+    although they held data.  Then the bloom chain itself on the same textures: folded, and bit-exact as everywhere else."""
+    import pbrhip
+    from pbrhip.synth import synth_post_inputs
+    L = gpu
+    W, H = 256, 144
+    taa, _, _, _, _ = synth_post_inputs(0x5EED00DC, W, H)
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), W, H, pbrhip.Format_RGBA16F)
+    pp = L.PBR_MakePostProcess(C.byref(gb), W, H, pbrhip.Format_BGRA8UN)
+    src = L.PBR_PostTaaOutput(pp, 0); dst = L.PBR_PostBloomUpscale(pp)
+    _upload(src, taa)
+    for m in range(dst.contents.mip_level_count):                  # stale data in every level of the target
+        lv = pbrhip.read_mip(dst, m)
+        pbrhip.upload_mip(dst, m, np.full(lv.shape, 3.5, np.float16))
+
+    class Off(C.Structure):
+        _fields_ = [("x", C.c_int), ("y", C.c_int), ("z", C.c_int)]
+
+    class Blit(C.Structure):                                       # GPU_OpBlitInfo [gpu.h:317-327]
+        _fields_ = [("filter", C.c_int), ("src_texture", pbrhip.TexP), ("dst_texture", pbrhip.TexP), ("src_layer", C.c_uint32), ("dst_layer", C.c_uint32),
+                    ("src_mip_level", C.c_uint32), ("dst_mip_level", C.c_uint32), ("src_area", Off * 2), ("dst_area", Off * 2)]
+    before = L.GPUX_FoldedBlitCount()
+    nbytes = L.GPUX_TextureMipBytes(dst, 0)
+    buf = L.GPU_MakeBuffer(nbytes, pbrhip.BufferFlag_CPU, None)
+    g = L.GPU_MakeGraph()
+    L.GPU_OpClearColorF(g, dst, 0xFFFFFFFF, 0.0, 0.0, 0.0, 0.0)
+    b = Blit(); b.filter = 0; b.src_texture = src; b.dst_texture = dst
+    b.src_area[1] = Off(W, H, 1); b.dst_area[1] = Off(W, H, 1)
+    L.GPU_OpBlit(g, C.byref(b))
+    L.GPUX_OpCopyTextureMipToBuffer(g, dst, 0, buf, 0)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g); L.GPU_DestroyGraph(g)
+    assert L.GPUX_FoldedBlitCount() == before                      # nothing consumed the copy additively: the blit stays
+    got = np.frombuffer((C.c_char * nbytes).from_address(buf.contents.data), dtype=np.float16).reshape(H, W, 4)
+    assert np.array_equal(got.view(np.uint16), np.asarray(taa, np.float16).view(np.uint16))
+    for m in range(1, dst.contents.mip_level_count):
+        assert not pbrhip.read_mip(dst, m).any(), m
+    L.GPU_DestroyBuffer(buf)
+    n = L.PBR_PostBloomPassCount(pp)
+    want_down, want_up = O.bloom_chain(taa, n)
+    g = L.GPU_MakeGraph()
+    L.PBR_RecordBloom(pp, g, 0)
+    L.GPU_GraphSubmit(g); L.GPU_GraphWait(g); L.GPU_DestroyGraph(g)
+    assert L.GPUX_FoldedBlitCount() == before + 1
+    _check_bloom(L, pbrhip, pp, want_down, want_up)
+    L.PBR_DestroyPostProcess(pp); L.PBR_DestroyGBuffer(C.byref(gb))
+
+
+@pytest.mark.gpu
 def test_gpu_frame_chain_hipgraph_replay_is_identical(gpu):
     """GPUX_SetGraphReplay: the per-frame chain (light-grid sweep, shade, TAA resolve, bloom, tone map; two graphs in flight as in
     main.cpp:49-51, 91-99, camera and ping-pong targets changing every frame) submitted through a captured / updated hipGraph
