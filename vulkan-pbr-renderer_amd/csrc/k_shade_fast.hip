@@ -61,23 +61,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const float k10 = 10.0f / 255.0f;
     const f3 emissive = mk3((float)(ee & 255u) * k10, (float)((ee >> 8) & 255u) * k10, (float)((ee >> 16) & 255u) * k10);
 
-    // :690 irradiance(N) (IBL mode): depends on the G-buffer alone, so its three loads are issued here, ahead of the long exact
-    // chain, and are consumed ~300 instructions later.  A smooth 32^2 map: one v_rcp projection.
-    f3 amb = mk3(0.0f, 0.0f, 0.0f);
-    if (kIBL) {
-        const float nf = (float)p.irr_size;
-        float fid = __builtin_amdgcn_cubeid(N.x, N.y, N.z);
-        float sc = __builtin_amdgcn_cubesc(N.x, N.y, N.z), tc = __builtin_amdgcn_cubetc(N.x, N.y, N.z);
-        float h = __builtin_amdgcn_rcpf(fabsf(__builtin_amdgcn_cubema(N.x, N.y, N.z))) * nf;
-        float off1 = 0.5f * nf + 0.5f;
-        float u = fmaf(sc, h, off1), v = fmaf(tc, h, off1);
-        float a = __builtin_amdgcn_fractf(u), b = __builtin_amdgcn_fractf(v);
-        float ncf = nf + 1.0f;
-        int off = (int)(fmaf(fmaf(fid, ncf, v - b), ncf, u - a) * (float)PBR_CELL_BYTES);       // (face * nc + j0) * nc + i0, exact in fp32
-        __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)p.irr_cells, 0, 6 * (p.irr_size + 1) * (p.irr_size + 1) * PBR_CELL_BYTES, 0x00020000);
-        amb = cells_bilerp(bl4(ri, off), bl4(ri, off + 16), bl4(ri, off + 32), a, b);
-    }
-
     // :444-451 (exact)
     const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
     float xn, yn, noise_1, noise_2, noise_3;
@@ -113,6 +96,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const f3 V = normalize3_nr(sub3(cam, P));                                          // :612 (exact)
     const bool sky = !(fabsf(P.x) <= 99.0f) || !(fabsf(P.y) <= 99.0f) || !(fabsf(P.z) <= 99.0f);   // :708 (== clamp(x) != x, NaN included)
 
+    // :690 irradiance(N) (IBL mode): depends on the G-buffer alone; its three loads are issued as soon as the wave knows that it holds a
+    // surface pixel at all (an all-sky wave -- most waves of a frame with sky -- skips them) and are consumed ~250 instructions later.
+    // A smooth 32^2 map: one v_rcp projection.
+    f3 amb = mk3(0.0f, 0.0f, 0.0f);
+    if (kIBL && __builtin_amdgcn_ballot_w64(!sky) != 0ull) {
+        const float nf = (float)p.irr_size;
+        float fid = __builtin_amdgcn_cubeid(N.x, N.y, N.z);
+        float sc = __builtin_amdgcn_cubesc(N.x, N.y, N.z), tc = __builtin_amdgcn_cubetc(N.x, N.y, N.z);
+        float h = __builtin_amdgcn_rcpf(fabsf(__builtin_amdgcn_cubema(N.x, N.y, N.z))) * nf;
+        float off1 = 0.5f * nf + 0.5f;
+        float u = fmaf(sc, h, off1), v = fmaf(tc, h, off1);
+        float a = __builtin_amdgcn_fractf(u), b = __builtin_amdgcn_fractf(v);
+        float ncf = nf + 1.0f;
+        int off = (int)(fmaf(fmaf(fid, ncf, v - b), ncf, u - a) * (float)PBR_CELL_BYTES);       // (face * nc + j0) * nc + i0, exact in fp32
+        __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)p.irr_cells, 0, 6 * (p.irr_size + 1) * (p.irr_size + 1) * PBR_CELL_BYTES, 0x00020000);
+        amb = cells_bilerp(bl4(ri, off), bl4(ri, off + 16), bl4(ri, off + 32), a, b);
+    }
+
     __amdgpu_buffer_rsrc_t rpre = __builtin_amdgcn_make_buffer_rsrc((void*)p.pre_cells, 0, p.pre_cells_bytes, 0x00020000);
     const float maxl = (float)(p.pre_levels - 1);
     const float wf = (float)p.pre_size;
@@ -128,7 +129,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         int l0 = (int)fl, l1 = min(l0 + 1, p.pre_levels - 1);
         // level sizes are powers of two: n_l = W * 2^-l exactly
         f3 c0 = pre_level_fetch(rpre, fid, s, t, ldexpf(wf, -l0), lv_off[l0]);
-        f3 c1 = pre_level_fetch(rpre, fid, s, t, ldexpf(wf, -l1), lv_off[l1]);          // w == 0 leaves c0 untouched: no branch
+        // The upper level only where some lane of the wave blends it in: a sky pixel asks for lod 1.0 exactly (w == 0), and most waves of a
+        // frame with sky are all-sky -- their three upper-level loads are half of what such a wave fetches.  fma(0, c1 - c0, c0) == c0.
+        if (__builtin_amdgcn_ballot_w64(w != 0.0f) == 0ull) return c0;
+        f3 c1 = pre_level_fetch(rpre, fid, s, t, ldexpf(wf, -l1), lv_off[l1]);          // a lane with w == 0 keeps c0: no per-lane branch
         return mk3(fmaf(w, c1.x - c0.x, c0.x), fmaf(w, c1.y - c0.y, c0.y), fmaf(w, c1.z - c0.z, c0.z));
     };
 
