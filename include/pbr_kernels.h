@@ -229,8 +229,8 @@ typedef struct PbrkBloomArgs {
     const void* blend_src;              /* blend_additive: the operand added to the pass's result, same layout as dst; NULL = dst itself */
 } PbrkBloomArgs;
 int pbrk_bloom_pass(const PbrkBloomArgs* args, void* stream);
-/* The three instantiations of a bloom pass give the same bits: one pixel per thread; 2 x 2 pixels per thread (exact 2 : 1 passes with even
- * sizes and at least quad_min_pixels target pixels; default 100000, env PBR_BLOOM_QUAD_MIN_PIXELS); four lanes per pixel (general-sampler
+/* The three instantiations of a bloom pass give the same bits: one pixel per thread; two (downsample) or 2 x 2 (upsample) pixels per thread
+ * (exact 2 : 1 passes with even sizes and at least quad_min_pixels target pixels; default 100000, env PBR_BLOOM_QUAD_MIN_PIXELS); four lanes per pixel (general-sampler
  * passes of at most small_max_pixels target pixels; default 40000, env PBR_BLOOM_SMALL_MAX_PIXELS).  Negative = default. */
 void pbrk_bloom_set_thresholds(long long quad_min_pixels, long long small_max_pixels);
 

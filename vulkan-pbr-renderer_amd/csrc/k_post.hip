@@ -558,17 +558,15 @@ __device__ __forceinline__ void bloom_row(const __amdgpu_buffer_rsrc_t rs, const
     }
 }
 
-// K10 / K11, exact 2:1 passes of LARGE levels: one thread per 2 x 2 block of target pixels.
-//   up:   the four pixels (2i + ox, 2j + oy) read the SAME 5 x 5 source window around texel (i, j); only their tap fractions differ
-//         (1/4 or 3/4 by parity): 15 loads and 75 conversions per four pixels instead of per pixel.
-//   down: the four pixels share an 8 x 8 source window, and 27 of their 4 x 13 taps coincide (a pixel's tap two texels to the right
-//         is its neighbour's centre tap): 32 loads instead of 72, 25 distinct taps instead of 52.
-// Every tap is the same lerp of the same texels with the same fraction as in k_bloom_pass, and every pixel's sum runs in the
-// shader's order: bit-identical (tests/test_post.py compares all twelve targets with the shader text at 1920 x 1080).
+// K11, exact 1 : 2 upsample of LARGE levels: one thread per 2 x 2 block of target pixels.  The four pixels (2i + ox, 2j + oy) read the SAME
+// 5 x 5 source window around texel (i, j); only their tap fractions differ (1/4 or 3/4 by parity): 15 loads and 75 conversions per four
+// pixels instead of per pixel.  Every tap is the same lerp of the same texels with the same fraction as in k_bloom_pass, and every pixel's sum
+// runs in the shader's order: bit-identical (tests/test_post.py compares all twelve targets with the shader text at 1920 x 1080).
 // Blocks at the border of the level read their window texel by texel with the sampler's edge clamp (the closed-form fractions hold for
 // every pixel; only the whole-row loads need the window inside the level).  Small levels stay with one pixel per thread: they are
-// latency-bound and a four-pixel thread is four times as long.
-template <bool kUp>
+// latency-bound and a four-pixel thread is four times as long.  (The downsample had a 2 x 2 form too -- 8 x 8 window, 25 distinct taps for
+// 52 -- which kept 158 registers and two waves per SIMD on the 960 x 540 pass, 65 % of their lifetime waiting for 32 loads: the pair form
+// below replaced it, 16.8 -> 14.2 us.)
 __global__ __launch_bounds__(256) void k_bloom_quad(BloomParams P) {
     const PbrkBloomArgs& A = P.a;
     const int qx = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -577,9 +575,8 @@ __global__ __launch_bounds__(256) void k_bloom_quad(BloomParams P) {
     const int SW = A.src.width, SH = A.src.height;
     const __amdgpu_buffer_rsrc_t rs = tex_rsrc(A.src, 8);
     float r[2][2][3];                                                                   // [oy][ox][rgb]
-    const bool interior = kUp ? (qx >= 2 && qx <= SW - 3 && qy >= 2 && qy <= SH - 3)
-                              : (qx >= 1 && 2 * qx + 1 <= A.dst_width - 2 && qy >= 1 && 2 * qy + 1 <= A.dst_height - 2);
-    if (kUp) {
+    const bool interior = qx >= 2 && qx <= SW - 3 && qy >= 2 && qy <= SH - 3;
+    {
         // horizontal taps of a row: [parity][left, centre, right]
         float hx[5][2][3][3];
 #pragma unroll
@@ -612,50 +609,6 @@ __global__ __launch_bounds__(256) void k_bloom_quad(BloomParams P) {
                     r[oy][ox][c] = sum * factor / 16.0f;
                 }
             }
-    } else {
-        // E[b][a]: tap at window position (2a, 2b); O[b][a]: tap at (2a + 1, 2b + 1).  Rows stream through: a tap needs two adjacent rows.
-        float E[4][4][3], O[3][3][3], prev[7][3];
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            float t[8][3], cur[7][3];
-            bloom_row<8>(rs, SW, SH, 4 * qx - 2, 4 * qy - 2 + rr, interior, t);
-#pragma unroll
-            for (int k = 0; k < 7; ++k)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) cur[k][c] = lerpc(t[k][c], t[k + 1][c], 0.5f);
-            if (rr >= 1) {
-                const int wy = rr - 1;                                                  // taps between rows wy and wy + 1
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if ((wy & 1) == 0) {
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) E[wy >> 1][a][c] = lerpc(prev[2 * a][c], cur[2 * a][c], 0.5f);
-                    } else {
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) O[wy >> 1][a][c] = lerpc(prev[2 * a + 1][c], cur[2 * a + 1][c], 0.5f);
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 7; ++k)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) prev[k][c] = cur[k][c];
-        }
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    auto ev = [&](int kx, int ky) { return E[dy + (ky >> 1)][dx + (kx >> 1)][c]; };    // tapd(kx, ky), kx and ky even
-                    auto od = [&](int kx, int ky) { return O[dy + (ky >> 1)][dx + (kx >> 1)][c]; };    // kx and ky odd
-                    float sum = ev(2, 2) * 0.125f;
-                    sum = sum + (((ev(0, 0) + ev(4, 0)) + ev(0, 4)) + ev(4, 4)) * 0.03125f;
-                    sum = sum + (((ev(2, 0) + ev(0, 2)) + ev(4, 2)) + ev(2, 4)) * 0.0625f;
-                    sum = sum + (((od(1, 1) + od(3, 1)) + od(1, 3)) + od(3, 3)) * 0.125f;
-                    if (A.dst_mip_level == 1) sum = fminf(sum, 1.0f);
-                    r[dy][dx][c] = sum;
-                }
     }
 #pragma unroll
     for (int oy = 0; oy < 2; ++oy) {
@@ -669,6 +622,63 @@ __global__ __launch_bounds__(256) void k_bloom_quad(BloomParams P) {
         const uint2 a = pack_half4(r[oy][0][0], r[oy][0][1], r[oy][0][2]), b = pack_half4(r[oy][1][0], r[oy][1][1], r[oy][1][2]);
         *o = make_uint4(a.x, a.y, b.x, b.y);
     }
+}
+
+// K10, exact 2 : 1 downsample of LARGE levels: two horizontally adjacent target pixels per thread.  They share an 8 x 6 source window (24
+// loads instead of 36) and 8 of their 2 x 13 taps coincide (a pixel's tap two texels to the right is its neighbour's centre tap): 18 distinct
+// taps.  E[b][a]: tap at window position (2a, 2b); O[b][a]: tap at (2a + 1, 2b + 1); rows stream through (a tap needs two adjacent rows).
+// Same lerps, same order of every pixel's sum as k_bloom_pass: bit-identical.
+__global__ __launch_bounds__(256) void k_bloom_down_pair(BloomParams P) {
+    const PbrkBloomArgs& A = P.a;
+    const int qx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int py = A.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (2 * qx >= A.dst_width || py >= A.y1) return;
+    const int SW = A.src.width, SH = A.src.height;
+    const __amdgpu_buffer_rsrc_t rs = tex_rsrc(A.src, 8);
+    const bool interior = qx >= 1 && 2 * qx + 1 <= A.dst_width - 2 && py >= 1 && py <= A.dst_height - 2;
+    float E[3][4][3], O[2][3][3], prev[7][3];
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) {
+        float t[8][3], cur[7][3];
+        bloom_row<8>(rs, SW, SH, 4 * qx - 2, 2 * py - 2 + rr, interior, t);
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) cur[k][c] = lerpc(t[k][c], t[k + 1][c], 0.5f);
+        if (rr >= 1) {
+            const int wy = rr - 1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if ((wy & 1) == 0) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) E[wy >> 1][a][c] = lerpc(prev[2 * a][c], cur[2 * a][c], 0.5f);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) O[wy >> 1][a][c] = lerpc(prev[2 * a + 1][c], cur[2 * a + 1][c], 0.5f);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) prev[k][c] = cur[k][c];
+    }
+    float r[2][3];
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            auto ev = [&](int kx, int ky) { return E[ky >> 1][dx + (kx >> 1)][c]; };
+            auto od = [&](int kx, int ky) { return O[ky >> 1][dx + (kx >> 1)][c]; };
+            float sum = ev(2, 2) * 0.125f;
+            sum = sum + (((ev(0, 0) + ev(4, 0)) + ev(0, 4)) + ev(4, 4)) * 0.03125f;
+            sum = sum + (((ev(2, 0) + ev(0, 2)) + ev(4, 2)) + ev(2, 4)) * 0.0625f;
+            sum = sum + (((od(1, 1) + od(3, 1)) + od(1, 3)) + od(3, 3)) * 0.125f;
+            if (A.dst_mip_level == 1) sum = fminf(sum, 1.0f);
+            r[dx][c] = sum;
+        }
+    const uint2 a = pack_half4(r[0][0], r[0][1], r[0][2]), b = pack_half4(r[1][0], r[1][1], r[1][2]);
+    *(uint4*)((uint2*)A.dst + (size_t)py * A.dst_width + 2 * qx) = make_uint4(a.x, a.y, b.x, b.y);
 }
 
 __global__ void k_debug_sample_post(PbrkTex2D t, const float* __restrict__ coords, int count, float4* __restrict__ out) {
@@ -741,14 +751,18 @@ extern "C" int pbrk_bloom_pass(const PbrkBloomArgs* a, void* stream) {
     const bool small = a->src.width <= 8192 && a->src.height <= 8192 && a->dst_width <= 8192 && a->dst_height <= 8192;
     p.exact2to1 = small && (a->upsample ? (a->dst_width == 2 * a->src.width && a->dst_height == 2 * a->src.height)
                                         : (a->src.width == 2 * a->dst_width && a->src.height == 2 * a->dst_height));
-    // 2 x 2 pixels per thread where the level is large enough to fill the chip with such threads (PBR_BLOOM_QUAD_MIN_PIXELS)
+    // two (downsample) / 2 x 2 (upsample) pixels per thread where the level is large enough to fill the chip with such threads (PBR_BLOOM_QUAD_MIN_PIXELS)
     if (g_quad_min < 0) { const char* e = getenv("PBR_BLOOM_QUAD_MIN_PIXELS"); g_quad_min = e ? atoll(e) : 100000; }
     const long long quad_min = g_quad_min;
-    const bool even = !((a->dst_width | a->dst_height | a->y0 | a->y1) & 1) && ((uintptr_t)a->dst & 15) == 0 && ((uintptr_t)a->src.data & 15) == 0 && ((uintptr_t)a->blend_src & 15) == 0;
-    if (p.exact2to1 && even && (long long)a->dst_width * (a->y1 - a->y0) >= quad_min) {
+    const bool wide = p.exact2to1 && ((uintptr_t)a->dst & 15) == 0 && ((uintptr_t)a->src.data & 15) == 0 && ((uintptr_t)a->blend_src & 15) == 0 &&
+                      (long long)a->dst_width * (a->y1 - a->y0) >= quad_min;
+    if (wide && !a->upsample && !a->blend_additive && !(a->dst_width & 1)) {
+        hipLaunchKernelGGL(k_bloom_down_pair, dim3((a->dst_width / 2 + 63) / 64, (a->y1 - a->y0 + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+        return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
+    }
+    if (wide && a->upsample && !((a->dst_width | a->dst_height | a->y0 | a->y1) & 1)) {
         dim3 qgrid((a->dst_width / 2 + 63) / 64, ((a->y1 - a->y0) / 2 + 3) / 4);
-        if (a->upsample) hipLaunchKernelGGL((k_bloom_quad<true>), qgrid, dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((k_bloom_quad<false>), qgrid, dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(k_bloom_quad, qgrid, dim3(256), 0, (hipStream_t)stream, p);
         return hipGetLastError() == hipSuccess ? PBRK_OK : PBRK_E_LAUNCH;
     }
     // four lanes per pixel where a level is too small to fill the chip and goes through the general sampler (PBR_BLOOM_SMALL_MAX_PIXELS)
