@@ -557,6 +557,10 @@ def main():
         except Exception as e:
             extra["post_process_error"] = repr(e)
         try:
+            extra["frame_loop"] = frame_loop_bench(L, pbrhip, env_tex)
+        except Exception as e:
+            extra["frame_loop_error"] = repr(e)
+        try:
             extra["lightgrid_sweep"] = sweep_bench(L, pbrhip)
         except Exception as e:
             extra["lightgrid_sweep_error"] = repr(e)
@@ -930,6 +934,60 @@ def post_bench(L, pbrhip, frames=20):
                                "achieved": byt / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": byt / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
     L.GPU_DestroyGraph(g); L.PBR_DestroyPostProcess(pp); L.PBR_DestroyGBuffer(C.byref(gb))
+    return res
+
+
+def frame_loop_bench(L, pbrhip, env_tex, frames=100):
+    """The demo's frame loop at 1920x1080, default (IBL) mode: light-grid sweep (K7) + shade (K5) + TAA resolve (K8) + bloom chain (K10 / K11)
+    + tone map (K9), frame f recorded and submitted while frame f - 1 runs (two graphs in flight, main.cpp:49-51, 91-99); wall time per
+    frame without per-op events.  tools/frame_chain_time.py is the same loop as a stand-alone tool (with the hipGraph replay variant)."""
+    from pbrhip import synth
+    W, H = 1920, 1080
+    gbd = synth.synth_gbuffer_spheres(W, H)
+    _, _, vel, vel_prev, history = synth.synth_post_inputs(0x5EED00D0, W, H)
+    scene = synth.synth_lightgrid(128, lit=False).view(np.uint16)
+    maps = pbrhip.PBR_IBLMaps()                                   # the reference's map sizes (render.cpp:794-796), as in shade_bench
+    L.PBR_MakeIBLMaps(C.byref(maps), 32, 256, 256)
+    L.PBR_GenIrradianceMap(env_tex, maps.irradiance_map)
+    L.PBR_GenPrefilteredEnvMap(env_tex, maps.tex_specular_env_map, 16)
+    L.PBR_GenBRDFIntegrationMap(maps.brdf_lut)
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), W, H, pbrhip.Format_RGBA16F)
+    for nm, key in (("base_color", "base"), ("normal", "normal"), ("orm", "orm"), ("emissive", "emissive"), ("depth", "depth")):
+        pbrhip.upload_mip(getattr(gb, nm), 0, gbd[key])
+    lp = L.PBR_MakeLightingPass(C.byref(gb), C.byref(maps), W, H)
+    pp = L.PBR_MakePostProcess(C.byref(gb), W, H, pbrhip.Format_BGRA8UN)
+    pbrhip.upload_mip(L.PBR_PostVelocity(pp, 0), 0, vel); pbrhip.upload_mip(L.PBR_PostVelocity(pp, 1), 0, vel_prev)
+    pbrhip.upload_mip(L.PBR_PostTaaOutput(pp, 1), 0, history)
+    lg = L.PBR_MakeLightgrid(128)
+    pbrhip.upload_mip(L.PBR_LightgridTexture(lg), 0, scene)
+    graphs = [L.GPU_MakeGraph(), L.GPU_MakeGraph()]
+    L.GPUX_EnableOpTiming(0)
+    try:
+        t0 = None
+        for f in range(frames + 8):
+            if f == 8:
+                L.GPU_WaitUntilIdle(); t0 = time.perf_counter()
+            g = graphs[f % 2]
+            if f >= 2:
+                L.GPU_GraphWait(g)                               # the frame before last
+            glob = pbrhip.fill_globals(gbd["cam_pos"], aspect=W / H, frame_idx=f % 59)
+            L.PBR_RecordLightgridSweep(lg, g)
+            L.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
+            L.PBR_RecordTaaResolve(pp, g, f); L.PBR_RecordBloom(pp, g, f); L.PBR_RecordFinalPostProcessBloom(pp, g, f)
+            L.GPU_GraphSubmit(g)
+        for g in graphs:
+            L.GPU_GraphWait(g)
+        per = (time.perf_counter() - t0) / frames
+    finally:
+        L.GPUX_EnableOpTiming(1)
+    bb = pbrhip.read_mip(L.PBR_PostBackbuffer(pp), 0)
+    res = {"workload": "1920x1080 frame loop, IBL mode: light-grid sweep + shade + TAA + bloom (6 + 6) + tone map, two graphs in flight", "frames": frames,
+           "us_per_frame": per * 1e6, "frames_per_s": 1.0 / per, "mpixels_per_s": W * H / per / 1e6, "backbuffer_checksum": int(bb.astype(np.uint64).sum())}
+    for g in graphs:
+        L.GPU_DestroyGraph(g)
+    L.PBR_DestroyLightgrid(lg); L.PBR_DestroyPostProcess(pp); L.PBR_DestroyLightingPass(lp); L.PBR_DestroyGBuffer(C.byref(gb))
+    L.PBR_DestroyIBLMaps(C.byref(maps))
     return res
 
 
