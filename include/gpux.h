@@ -102,5 +102,10 @@ GPU_API void GPUX_SetGraphReplay(int enable);
 GPU_API void GPUX_GraphReplayStats(GPU_Graph* graph, uint64_t* launches, uint64_t* updates, uint64_t* instantiations);
 /* 1:1 blits folded into the additive bloom draw that consumes their copy, since the library was loaded (env PBR_GRAPH_FOLD=0 keeps every blit) */
 GPU_API uint64_t GPUX_FoldedBlitCount(void);
+/* Graphs in flight: the leading ops of a graph that share no texture with the TAIL of the graph submitted before it (from its first bloom
+ * draw on) start once that graph's head is done instead of after its end (GPU_GraphSubmit); everything else keeps submission order.
+ * on: 1 / 0, -1 = default (env PBR_GRAPH_OVERLAP, else 1).  GPUX_OverlappedSubmitCount: submissions that started this way. */
+GPU_API void GPUX_SetGraphOverlap(int on);
+GPU_API uint64_t GPUX_OverlappedSubmitCount(void);
 
 #endif

@@ -407,6 +407,75 @@ def test_gpu_graph_folds_keep_a_blit_and_a_clear_that_something_else_can_see(gpu
 
 
 @pytest.mark.gpu
+def test_gpu_frames_in_flight_overlap_head_with_previous_tail(gpu):
+    """Two graphs in flight at 1920x1080 (kernels long enough to really run side by side): with GPUX_SetGraphOverlap(1) a frame's sweep,
+    shade and TAA resolve start when the previous frame's TAA is done and run beside its bloom chain and tone map; with 0 every graph
+    waits for all of its predecessor.  Same backbuffer, bit for bit, at every checkpoint of a 40-frame run with a moving camera; and the
+    overlap did engage (one submission per frame after the first)."""
+    import pbrhip
+    from pbrhip import synth
+    L = gpu
+    L.GPUX_EnableOpTiming(0)
+    W, H = 1920, 1080
+    gbd = synth.synth_gbuffer_spheres(W, H)
+    _, _, vel, vel_prev, history = synth.synth_post_inputs(0x5EED00D2, W, H)
+    env = synth.synth_env(64, seed=0x5EED00AA)
+    env_tex = pbrhip.make_texture(pbrhip.Format_RGBA32F, 64, 64, pbrhip.TextureFlag_Cubemap | pbrhip.TextureFlag_HasMipmaps, env)
+    maps = pbrhip.PBR_IBLMaps()
+    L.PBR_MakeIBLMaps(C.byref(maps), 32, 256, 256)
+    L.PBR_GenIrradianceMap(env_tex, maps.irradiance_map); L.PBR_GenPrefilteredEnvMap(env_tex, maps.tex_specular_env_map, 16); L.PBR_GenBRDFIntegrationMap(maps.brdf_lut)
+    gb = pbrhip.PBR_GBuffer()
+    L.PBR_MakeGBuffer(C.byref(gb), W, H, pbrhip.Format_RGBA16F)
+    for nm, key in (("base_color", "base"), ("normal", "normal"), ("orm", "orm"), ("emissive", "emissive"), ("depth", "depth")):
+        pbrhip.upload_mip(getattr(gb, nm), 0, gbd[key])
+    lp = L.PBR_MakeLightingPass(C.byref(gb), C.byref(maps), W, H)
+    pp = L.PBR_MakePostProcess(C.byref(gb), W, H, pbrhip.Format_BGRA8UN)
+    pbrhip.upload_mip(L.PBR_PostVelocity(pp, 0), 0, vel); pbrhip.upload_mip(L.PBR_PostVelocity(pp, 1), 0, vel_prev)
+    lg = L.PBR_MakeLightgrid(128)
+    scene = synth.synth_lightgrid(128, lit=False).view(np.uint16)
+    graphs = [L.GPU_MakeGraph(), L.GPU_MakeGraph()]
+    frames = 40
+
+    def run(overlap):
+        L.GPUX_SetGraphOverlap(overlap)
+        pbrhip.upload_mip(L.PBR_PostTaaOutput(pp, 1), 0, history)
+        pbrhip.upload_mip(L.PBR_LightgridTexture(lg), 0, scene)
+        before = L.GPUX_OverlappedSubmitCount()
+        sums = []
+        for f in range(frames):
+            g = graphs[f % 2]
+            if f >= 2:
+                L.GPU_GraphWait(g)
+            cam = (float(gbd["cam_pos"][0]) + 0.01 * f, float(gbd["cam_pos"][1]), float(gbd["cam_pos"][2]))
+            glob = pbrhip.fill_globals(cam, aspect=W / H, frame_idx=f % 59)
+            L.PBR_RecordLightgridSweep(lg, g)
+            L.PBR_RecordLightingPass(lp, g, C.byref(glob), 0, 0)
+            L.PBR_RecordTaaResolve(pp, g, f); L.PBR_RecordBloom(pp, g, f); L.PBR_RecordFinalPostProcessBloom(pp, g, f)
+            L.GPU_GraphSubmit(g)
+            if f % 8 == 7:
+                L.GPU_GraphWait(graphs[(f + 1) % 2]); L.GPU_GraphWait(g)
+                bb = pbrhip.read_mip(L.PBR_PostBackbuffer(pp), 0)
+                sums.append((int(bb.astype(np.uint64).sum()), bb[::97, ::89].copy()))
+        for g in graphs:
+            L.GPU_GraphWait(g)
+        return sums, L.GPUX_OverlappedSubmitCount() - before
+
+    try:
+        ordered, n0 = run(0)
+        overlapped, n1 = run(1)
+    finally:
+        L.GPUX_SetGraphOverlap(-1); L.GPUX_EnableOpTiming(1)
+    assert n0 == 0 and n1 >= frames - 6, (n0, n1)
+    assert len(ordered) == len(overlapped) == 5 and ordered[-1][0] > 0
+    for (sa, a), (sb, b) in zip(ordered, overlapped):
+        assert sa == sb and np.array_equal(a, b)
+    for g in graphs:
+        L.GPU_DestroyGraph(g)
+    L.PBR_DestroyLightgrid(lg); L.PBR_DestroyPostProcess(pp); L.PBR_DestroyLightingPass(lp); L.PBR_DestroyGBuffer(C.byref(gb))
+    L.PBR_DestroyIBLMaps(C.byref(maps)); L.GPU_DestroyTexture(env_tex)
+
+
+@pytest.mark.gpu
 def test_gpu_frame_chain_hipgraph_replay_is_identical(gpu):
     """GPUX_SetGraphReplay: the per-frame chain (light-grid sweep, shade, TAA resolve, bloom, tone map; two graphs in flight as in
     main.cpp:49-51, 91-99, camera and ping-pong targets changing every frame) submitted through a captured / updated hipGraph

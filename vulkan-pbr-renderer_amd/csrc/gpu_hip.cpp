@@ -120,6 +120,11 @@ struct GPU_Graph {
     std::vector<hipStream_t> side;                 // side streams for overlapping independent tile dispatches (created on first use)
     std::vector<hipEvent_t> sync_ev;               // untimed fork/join events
     hipEvent_t order_ev = nullptr;                 // recorded on this graph's stream when the NEXT submitted graph must follow it
+    // head / tail split of the last submission (GPU_GraphSubmit): `mid_ev` is recorded in front of the first bloom draw; the next graph's
+    // leading ops that touch none of the textures in tail_reads / tail_writes wait for it instead of for the whole graph
+    hipEvent_t mid_ev = nullptr;
+    bool mid_recorded = false;
+    std::vector<TextureImpl*> tail_reads, tail_writes;
     size_t sync_used = 0;
     std::vector<Op> ops;
     bool submitted = false;
@@ -739,6 +744,7 @@ GPU_API void GPU_DestroyGraph(GPU_Graph* g) {
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : g->sync_ev) (void)hipEventDestroy(e);
     if (g->order_ev) (void)hipEventDestroy(g->order_ev);
+    if (g->mid_ev) (void)hipEventDestroy(g->mid_ev);
     if (g->span_a) (void)hipEventDestroy(g->span_a);
     if (g->span_b) (void)hipEventDestroy(g->span_b);
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
@@ -1701,6 +1707,35 @@ static void fold_blits(GPU_Graph* g) {
     }
 }
 
+// Textures an op reads / writes, at whole-texture granularity; false when the op touches memory this analysis does not follow (buffers,
+// host pointers).  Draws and dispatches: every texture bound in their descriptor set counts as read, a dispatch's also as written
+// (storage images), a draw's render targets as written.
+static bool op_access(const Op& op, std::vector<TextureImpl*>& r, std::vector<TextureImpl*>& w) {
+    switch (op.kind) {
+    case Op_Dispatch: case Op_Shade:
+        if (!op.set) return false;
+        for (const Slot& sl : op.set->slots) {
+            if (sl.buf) return false;
+            if (sl.tex) { r.push_back(sl.tex); if (op.kind == Op_Dispatch) w.push_back(sl.tex); }
+        }
+        if (op.kind == Op_Shade) {
+            if (!op.pass) return false;
+            for (const GPU_TextureView& tv : op.pass->targets) w.push_back((TextureImpl*)tv.texture);
+            if (op.blend_tex) r.push_back(op.blend_tex);
+        }
+        return true;
+    case Op_MipGen: r.push_back(op.tex); w.push_back(op.tex); return true;
+    case Op_Blit: r.push_back(op.tex); w.push_back(op.tex2); return true;
+    case Op_Clear: w.push_back(op.tex); return true;
+    default: return false;
+    }
+}
+static int g_overlap_on = -1;                   // -1: PBR_GRAPH_OVERLAP or the default (1)
+static uint64_t g_overlapped_submits = 0;
+GPU_API void GPUX_SetGraphOverlap(int on) { g_overlap_on = on; }
+GPU_API uint64_t GPUX_OverlappedSubmitCount(void) { return g_overlapped_submits; }
+static bool contains(const std::vector<TextureImpl*>& v, const TextureImpl* t) { for (const TextureImpl* x : v) if (x == t) return true; return false; }
+
 GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
     GPU_REQUIRE_V(g && !g->submitted, "GPU_GraphSubmit: graph is NULL or already submitted");
     GPU_REQUIRE_V(g->in_pass == nullptr && g->preparing == nullptr, "GPU_GraphSubmit: render pass still open");
@@ -1714,14 +1749,51 @@ GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
     // GPUX_GraphStream.  Side streams fork from g->stream, so they inherit the dependency.
     static int order_on = -1;                                     // PBR_GRAPH_ORDER=0: diagnostic only (shows that the ordering test can fail)
     if (order_on < 0) { const char* e = getenv("PBR_GRAPH_ORDER"); order_on = e ? atoi(e) : 1; }
+    fold_blits(g);
+    // Frames in flight (main.cpp:49-51, 91-99 keeps two graphs): the tail of a frame's graph -- its bloom chain, a dozen small dependent
+    // launches that leave most of the chip idle -- touches only the bloom targets, the TAA result it reads and the backbuffer.  The next
+    // graph's leading ops (light-grid sweep, shade, TAA resolve) touch none of those: they wait for the event in front of the previous
+    // graph's first bloom draw instead of for its end, and run beside that tail; the first op that shares a texture with the tail (and
+    // everything behind it) waits for the end as before.  Whole-texture granularity, every texture bound to an op counts; an op this
+    // analysis does not follow ends the overlap.  PBR_GRAPH_OVERLAP=0: every graph waits for all of its predecessor.
+    if (g_overlap_on < 0) { const char* e = getenv("PBR_GRAPH_OVERLAP"); g_overlap_on = e ? atoi(e) : 1; }
+    const int overlap_on = g_overlap_on;
+    if (G.replay < 0) { const char* e = getenv("PBR_GRAPH_REPLAY"); G.replay = e ? (atoi(e) != 0) : 0; }
+    size_t order_before = 0;                                      // index of the first op that must wait for the previous graph's end
+    GPU_Graph* order_prev = nullptr;
     if (order_on && G.last_submitted && G.last_submitted != g) {
         GPU_Graph* prev = G.last_submitted;
         if (!prev->order_ev) HIP_OK(hipEventCreateWithFlags(&prev->order_ev, hipEventDisableTiming));
         HIP_OK(hipEventRecord(prev->order_ev, prev->stream));
-        HIP_OK(hipStreamWaitEvent(g->stream, prev->order_ev, 0));
+        if (overlap_on && prev->mid_recorded && G.replay != 1) {
+            std::vector<TextureImpl*> r, w;
+            for (; order_before < g->ops.size(); ++order_before) {
+                r.clear(); w.clear();
+                if (!op_access(g->ops[order_before], r, w)) break;
+                bool clash = false;
+                for (TextureImpl* t : w) clash |= contains(prev->tail_reads, t) || contains(prev->tail_writes, t);
+                for (TextureImpl* t : r) clash |= contains(prev->tail_writes, t);
+                if (clash) break;
+            }
+        }
+        if (order_before > 0) { HIP_OK(hipStreamWaitEvent(g->stream, prev->mid_ev, 0)); order_prev = prev; ++g_overlapped_submits; }
+        else HIP_OK(hipStreamWaitEvent(g->stream, prev->order_ev, 0));
     }
     G.last_submitted = g;
-    fold_blits(g);
+    // this graph's own head / tail split: the tail starts at the first bloom draw
+    size_t mid_idx = g->ops.size();
+    for (size_t i = 0; i < g->ops.size(); ++i)
+        if (g->ops[i].kind == Op_Shade && (g->ops[i].gpipe->kernel == Kernel_BloomDown || g->ops[i].gpipe->kernel == Kernel_BloomUp)) { mid_idx = i; break; }
+    g->mid_recorded = false; g->tail_reads.clear(); g->tail_writes.clear();
+    if (overlap_on && mid_idx > 0 && mid_idx < g->ops.size()) {
+        bool known = true;
+        for (size_t i = mid_idx; i < g->ops.size() && known; ++i) known = op_access(g->ops[i], g->tail_reads, g->tail_writes);
+        if (!known) { mid_idx = g->ops.size(); g->tail_reads.clear(); g->tail_writes.clear(); }
+    } else mid_idx = g->ops.size();
+    // the chain property the next submission relies on: this graph's mid event (or, without one, its end) implies the END of the graph
+    // before it -- so the wait for that end never comes later than the mid event
+    if (order_before > mid_idx) order_before = mid_idx;
+    size_t op_index = 0;
     if (G.replay < 0) { const char* e = getenv("PBR_GRAPH_REPLAY"); G.replay = e ? (atoi(e) != 0) : 0; }
     bool capture = G.replay == 1 && !G.timing && !g->replay_broken && !g->ops.empty();
     if (capture) capture = graph_replayable(g);
@@ -1746,6 +1818,18 @@ GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
         writes.clear(); reads.clear(); open = false; g->cur = g->stream;
     };
     for (Op& op : g->ops) {
+        if (order_prev && op_index == order_before) {                  // from here on: after everything the previous graph enqueued
+            close_region();
+            HIP_OK(hipStreamWaitEvent(g->stream, order_prev->order_ev, 0));
+            order_prev = nullptr;
+        }
+        if (op_index == mid_idx && !capture) {                         // head done: the next graph's independent ops may start
+            close_region();
+            if (!g->mid_ev) HIP_OK(hipEventCreateWithFlags(&g->mid_ev, hipEventDisableTiming));
+            HIP_OK(hipEventRecord(g->mid_ev, g->stream));
+            g->mid_recorded = true;
+        }
+        ++op_index;
         bool tile = n_side >= 2 && op.kind == Op_Dispatch && op.rows_explicit &&
                     (op.cpipe->kernel == Kernel_Prefilter || op.cpipe->kernel == Kernel_Irradiance);
         Slot* out = tile ? named_slot(op.set, "OUTPUT") : nullptr;
@@ -1787,6 +1871,7 @@ GPU_API void GPU_GraphSubmit(GPU_Graph* g) {
         g->cur = g->stream;
     }
     close_region();
+    if (order_prev) { HIP_OK(hipStreamWaitEvent(g->stream, order_prev->order_ev, 0)); order_prev = nullptr; }   // every op was independent: still end after it
     if (G.timing) { HIP_OK(hipEventRecord(g->span_b, g->stream)); g->span_recorded = true; }
     if (capture) {
         hipGraph_t cg = nullptr;

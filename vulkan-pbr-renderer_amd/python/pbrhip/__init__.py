@@ -164,7 +164,7 @@ PROTOTYPES = {
     "GPUX_OpDispatchLines": (None, [VP, U32, U32, U32, U32]),
     "GPUX_SetShadeFlags": (None, [VP, C.c_int]), "GPUX_OpDrawRows": (None, [VP, U32, U32]),
     "GPUX_OpCopyTextureMipToBuffer": (None, [VP, TexP, U32, BufP, U32]), "GPUX_OpCopyBufferToTextureMip": (None, [VP, BufP, U32, TexP, U32]),
-    "GPUX_FoldedBlitCount": (C.c_uint64, []), "GPUX_TextureMipBytes": (C.c_uint64, [TexP, U32]), "GPUX_TextureDevicePtr": (VP, [TexP, U32]), "GPUX_BufferDevicePtr": (VP, [BufP]),
+    "GPUX_FoldedBlitCount": (C.c_uint64, []), "GPUX_SetGraphOverlap": (None, [C.c_int]), "GPUX_OverlappedSubmitCount": (C.c_uint64, []), "GPUX_TextureMipBytes": (C.c_uint64, [TexP, U32]), "GPUX_TextureDevicePtr": (VP, [TexP, U32]), "GPUX_BufferDevicePtr": (VP, [BufP]),
     "GPUX_MakeTextureExternal": (TexP, [C.c_int, U32, U32, U32, C.c_int, VP, C.c_uint64]),
     "GPUX_InvalidateTexture": (None, [TexP]),
     "GPUX_TextureTotalBytes": (C.c_uint64, [TexP]), "GPUX_TextureMipOffset": (C.c_uint64, [TexP, U32]),
